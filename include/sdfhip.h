@@ -1,0 +1,144 @@
+/* sdfhip.h — C ABI of the MI355X-native batched point-query path of sxyu/sdf.
+ *
+ * This is the drop-in boundary: every entry point below replaces one member of the
+ * reference's `sdf::SDF` (include/sdf/sdf.hpp:150-258, src/sdf.cpp:331-395) and is what the
+ * reference's own C++ façade / pybind module (pybind.cpp:18-83) would bind.  Plain pointers
+ * and sizes only; no C++ or torch types.  All "file:line" citations are into /root/reference.
+ *
+ * Conventions
+ *   - return 0 on success, a negative SDFHIP_E_* code on failure; never throws.
+ *     `sdfhip_last_error()` returns a thread-local message for the last failure.
+ *   - points / verts are row-major float32 [N,3]; faces row-major uint32 [F,3]
+ *     (sdf.hpp:43-46).  Results: float32 [N] (SDF, positive inside, sdf.hpp:174),
+ *     uint8 [N] (contains, 0/1), int32 [N] (nn, index into the input verts).
+ *   - the caller owns every buffer.  Host entry points take host pointers; the `_device`
+ *     variants take device pointers on the handle's GPU plus a HIP stream (hipStream_t
+ *     passed as void*, NULL = the null stream) and are asynchronous on that stream.
+ *   - a handle is bound to one GPU.  Query calls on one handle are serialised by the
+ *     library (they share the handle's query workspace); `sdfhip_update` is exclusive.
+ *   - `n_threads` of the reference API (sdf.hpp:187-204) has no meaning on the GPU and is
+ *     accepted and ignored by the façades above this ABI.
+ *   - there is NO CPU fallback: without a usable HIP device `sdfhip_create` fails.
+ */
+#ifndef SDFHIP_H_
+#define SDFHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdfhip_ctx sdfhip_t;
+
+enum {
+    SDFHIP_OK = 0,
+    SDFHIP_E_INVALID = -1, /* bad argument */
+    SDFHIP_E_HIP = -2,     /* a HIP runtime call failed */
+    SDFHIP_E_NODEVICE = -3,
+    SDFHIP_E_NOMEM = -4,
+    SDFHIP_E_STATE = -5 /* e.g. mutable access on a non-owning handle */
+};
+
+/* Replaces SDF::SDF(verts, faces, robust, copy) (sdf.hpp:168-169, sdf.cpp:331-341) and
+ * Impl::Impl (sdf.cpp:17-29): builds vertex->incident-face lists, then runs update().
+ * copy = 0: the handle keeps `verts`/`faces` pointers for its lifetime and re-reads `verts`
+ *           on every sdfhip_update (Eigen::Ref semantics, sdf.cpp:339).
+ * copy = 1: the handle owns host copies (sdf.cpp:334-337); see sdfhip_verts_mutable.
+ * device  : HIP device ordinal, or -1 for the current device.
+ * The ray-cast rotation (sdf.cpp:43-48) is drawn from a time-seeded RNG as in the
+ * reference (util.cpp:32-40) unless pinned with sdfhip_set_raycast_axes. */
+int sdfhip_create(const float* verts, uint32_t n_verts, const uint32_t* faces, uint32_t n_faces,
+                  int robust, int copy, int device, sdfhip_t** out);
+
+/* Replaces SDF::~SDF (sdf.cpp:343). */
+void sdfhip_destroy(sdfhip_t* h);
+
+/* Replaces SDF::update() -> Impl::update(true) (sdf.cpp:391, 31-73): re-reads the vertex
+ * positions, rebuilds the vertex kd-tree, mesh AABB, per-face normals/areas, draws a new
+ * rotation (unless pinned) and refits the face LBVH. */
+int sdfhip_update(sdfhip_t* h);
+
+/* Same as sdfhip_update but the new vertex positions are read from a device buffer
+ * (float32 [n_verts,3]) on `stream`; the host copy / borrowed host pointer is refreshed
+ * too when the handle owns its data.  No counterpart in the reference (its vertices live
+ * in host memory); for deforming meshes produced on the GPU (BASELINE.json config 5). */
+int sdfhip_update_from_device(sdfhip_t* h, const float* d_verts, void* stream);
+
+/* The reference's rotation is private and non-deterministic (sdf.cpp:271, util.cpp:32-40),
+ * so parity is only defined "given the same R".  set: pins R (row-major 3x3, used as
+ * `p * R`, sdf.cpp:284-285) for this and all later updates and re-runs the rotation-
+ * dependent part of update().  pin = 0 un-pins (later updates draw a fresh R). */
+int sdfhip_set_raycast_axes(sdfhip_t* h, const float R[9], int pin);
+int sdfhip_get_raycast_axes(const sdfhip_t* h, float R[9]);
+
+/* Replaces SDF::operator()(points, trunc_aabb, n_threads) -> Impl::calc
+ * (sdf.cpp:377-379, 93-158). */
+int sdfhip_sdf(sdfhip_t* h, const float* points, int64_t n, int trunc_aabb, float* out);
+int sdfhip_sdf_device(sdfhip_t* h, const float* d_points, int64_t n, int trunc_aabb,
+                      float* d_out, void* stream);
+
+/* Replaces SDF::contains(points, n_threads) -> Impl::contains (sdf.cpp:385-389, 160-174). */
+int sdfhip_contains(sdfhip_t* h, const float* points, int64_t n, uint8_t* out);
+int sdfhip_contains_device(sdfhip_t* h, const float* d_points, int64_t n, uint8_t* d_out,
+                           void* stream);
+
+/* Replaces SDF::nn(points, n_threads) -> Impl::nn (sdf.cpp:381-383, 75-91). */
+int sdfhip_nn(sdfhip_t* h, const float* points, int64_t n, int32_t* out);
+int sdfhip_nn_device(sdfhip_t* h, const float* d_points, int64_t n, int32_t* d_out, void* stream);
+
+/* Debug/verification aid (no counterpart: the reference's per-ray parities are locals of
+ * Impl::_raycast, sdf.cpp:292-327): out3[i] = {z+, z-, x+ or -1 if not cast}; all -1 when
+ * the point is outside the closed mesh AABB.  Robust handles only. */
+int sdfhip_raycast_detail(sdfhip_t* h, const float* points, int64_t n, int32_t* out3);
+
+/* Data accessors (sdf.hpp:215-245, sdf.cpp:345-375). */
+int sdfhip_robust(const sdfhip_t* h);
+int sdfhip_own_data(const sdfhip_t* h);
+int sdfhip_device(const sdfhip_t* h);
+uint32_t sdfhip_num_verts(const sdfhip_t* h);
+uint32_t sdfhip_num_faces(const sdfhip_t* h);
+/* SDF::verts() / faces(): the host arrays the handle currently reads (sdf.cpp:359, 368). */
+const float* sdfhip_verts(const sdfhip_t* h);
+const uint32_t* sdfhip_faces(const sdfhip_t* h);
+/* SDF::verts_mutable() (sdf.cpp:369-375): pointer to the owned copy; NULL and
+ * SDFHIP_E_STATE (message "'verts' is non mutable, construct with copy=True") when the
+ * handle does not own its data.  Call sdfhip_update after writing. */
+float* sdfhip_verts_mutable(sdfhip_t* h);
+/* SDF::faces_mutable() (sdf.cpp:360-366).  As in the reference, faces must not actually
+ * change for the lifetime of the handle (sdf.hpp:162-163). */
+uint32_t* sdfhip_faces_mutable(sdfhip_t* h);
+/* SDF::surface_area() (sdf.cpp:349): sum of face_areas (each 2x the geometric area,
+ * sdf.cpp:68). */
+int sdfhip_surface_area(sdfhip_t* h, float* out);
+/* SDF::face_areas() / face_normals() / aabb() (sdf.cpp:351-357): copied into caller
+ * buffers of F, 3F and 6 floats. */
+int sdfhip_face_areas(sdfhip_t* h, float* out);
+int sdfhip_face_normals(sdfhip_t* h, float* out);
+int sdfhip_aabb(const sdfhip_t* h, float out[6]);
+/* SDF::adj_faces(pointid) (sdf.cpp:345-347): incident face ids, ascending.
+ * Returns the count (>= 0) or a negative error; *ids points into handle-owned memory. */
+int sdfhip_adj_faces(const sdfhip_t* h, uint32_t vert, const int32_t** ids);
+
+/* Statistics of the structures behind the handle (no counterpart in the reference). */
+typedef struct {
+    int32_t kd_nodes;      /* internal nodes of the vertex kd-tree */
+    int32_t kd_depth;      /* max number of internal nodes on a root-to-leaf path */
+    int32_t bvh_nodes;     /* nodes of the threaded face LBVH (0 when non-robust) */
+    int32_t bvh_depth;
+    float last_update_ms;  /* wall time of the last create/update */
+    float last_kd_build_ms;
+} sdfhip_stats_t;
+int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* out);
+
+/* Tuning knobs (no counterpart). key: "sort_queries" (0/1, default 1: Morton-sort query
+ * chunks of >= sort_min points), "sort_min", "chunk" (points per internal chunk). */
+int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t value);
+
+const char* sdfhip_last_error(void);
+const char* sdfhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFHIP_H_ */

@@ -1,0 +1,8 @@
+"""sdf_amd — MI355X-native batched point queries of sxyu/sdf (`SDF.__call__`, `contains`, `nn`).
+
+`from sdf_amd import SDF` is the drop-in for `from pysdf import SDF`.
+"""
+from .pysdf import SDF, SdfHipError, load_library, num_threads  # noqa: F401
+from . import meshes  # noqa: F401
+
+__all__ = ["SDF", "SdfHipError", "load_library", "num_threads", "meshes"]

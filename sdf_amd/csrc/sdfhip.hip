@@ -1,0 +1,1455 @@
+// sdfhip.hip — MI355X (gfx950) implementation of the batched point-query path of sxyu/sdf
+// behind the C ABI of include/sdfhip.h.  Written from scratch for CDNA4; compile with
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off
+// (-ffp-contract=off is REQUIRED: results must be bit-identical to a non-FMA x86-64 build
+// of the reference, CMakeLists.txt:33).  "file:line" citations are into /root/reference.
+//
+// Structures (all resident in HBM, sized to sit in L2 / Infinity Cache):
+//   kd_nodes   16 B / internal node of the strict nanoflann-equivalent vertex kd-tree
+//   kd_pts     12 B / vertex, in tree (vind) order: a leaf is a contiguous run
+//   geo        64 B / face: a, b, c, unit normal, area (world frame) for dist_point2tri
+//   rnodes     32 B / node: threaded (stackless, pre-order + skip link) LBVH over the
+//              rotated-frame face AABBs; Morton codes -> LDS radix sort -> Karras hierarchy,
+//              refit on update()
+//   rface      48 B / face: a', b', c', n' in the rotated ray-cast frame
+// Kernels are one lane per query; the kd traversal keeps its stack in LDS
+// ([level][lane] layout, conflict free for any mix of per-lane depths).
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/sdfhip.h"
+#include "geom.h"
+#include "kd_host.h"
+
+using sdfk::V3;
+
+// =========================================================================================
+// errors
+// =========================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPC(expr)                                                                          \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? SDFHIP_E_NOMEM : SDFHIP_E_HIP,          \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,    \
+                        __LINE__);                                                          \
+    } while (0)
+
+// =========================================================================================
+// device-side views
+// =========================================================================================
+struct RayNode {  // 32 B
+    float mnx, mny, mxx, mxy;
+    float mnz, mxz;
+    uint32_t skip;  // next node when this subtree is skipped (pre-order index)
+    uint32_t face;  // face id for a leaf, NOFACE for an internal node
+};
+constexpr uint32_t NOFACE = 0xFFFFFFFFu;
+
+struct MeshDev {
+    // vertex kd-tree
+    const uint4* kd_nodes;
+    const float* kd_pts;
+    const int32_t* kd_vind;
+    uint32_t kd_root;
+    float bb[6];  // mesh AABB == kd root bbox
+    // adjacency + face geometry
+    const uint32_t* adj_off;
+    const int32_t* adj_faces;
+    const float4* geo;
+    // ray structure
+    const float4* rnodes;
+    uint32_t n_rnodes;
+    const float4* rface;
+    float R[9];
+};
+
+constexpr uint32_t KD_LEAF = sdfk::KD_LEAF_BIT;
+constexpr uint32_t KD_FEATM = 3u << sdfk::KD_FEAT_SHIFT;
+constexpr uint32_t KD_MARK = sdfk::KD_REF_MASK;  // reserved internal index = restore marker
+
+constexpr int QBLOCK = 128;       // threads per block of the query kernels (2 waves)
+constexpr int LDS_DEPTH_MAX = 40; // deeper kd-trees use the global-memory stack variant
+
+// =========================================================================================
+// kd nearest vertex: exact iterative form of nanoflann's searchLevel
+// (nanoflann.hpp:1346-1409) with KNNResultSet<float>(1) (142-205), eps = 0.
+//
+// The recursion's state is (node, mindistsq, dists[3]).  dists[] is kept in registers and
+// restored exactly as the recursion does (nanoflann.hpp:1396-1407) by "restore markers":
+//   push    when descending to the near child: {far ref | feat, mindistsq', cut_dist}
+//   pop     a far entry is tested with `mindistsq' <= worst` at pop time, which is when the
+//           recursion evaluates it (the near subtree has completely returned); if taken, its
+//           slot is overwritten with a marker {MARK | feat, old dists[feat]} that restores
+//           dists[feat] once the far subtree has returned.
+// Hence at most one slot per internal node on the current root-to-leaf path: capacity =
+// kd depth.  `stk` points at this lane's word of slot 0; consecutive words are `stride`
+// dwords apart.
+// =========================================================================================
+template <class PTR>
+__device__ __forceinline__ int kd_nearest(const MeshDev& M, float qx, float qy, float qz, PTR stk,
+                                          uint32_t stride, float& best_out) {
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, mind = 0.f;
+    // computeInitialDistances (nanoflann.hpp:1005-1022)
+    if (qx < M.bb[0]) {
+        d0 = (qx - M.bb[0]) * (qx - M.bb[0]);
+        mind += d0;
+    }
+    if (qx > M.bb[3]) {
+        d0 = (qx - M.bb[3]) * (qx - M.bb[3]);
+        mind += d0;
+    }
+    if (qy < M.bb[1]) {
+        d1 = (qy - M.bb[1]) * (qy - M.bb[1]);
+        mind += d1;
+    }
+    if (qy > M.bb[4]) {
+        d1 = (qy - M.bb[4]) * (qy - M.bb[4]);
+        mind += d1;
+    }
+    if (qz < M.bb[2]) {
+        d2 = (qz - M.bb[2]) * (qz - M.bb[2]);
+        mind += d2;
+    }
+    if (qz > M.bb[5]) {
+        d2 = (qz - M.bb[5]) * (qz - M.bb[5]);
+        mind += d2;
+    }
+    float best = FLT_MAX;  // KNNResultSet::init (nanoflann.hpp:158-164)
+    int bestpos = -1;
+    uint32_t cur = M.kd_root;
+    int sp = 0;
+    for (;;) {
+        while (!(cur & KD_LEAF)) {
+            const uint4 nd = M.kd_nodes[cur];
+            const float divlow = __uint_as_float(nd.x), divhigh = __uint_as_float(nd.y);
+            const uint32_t feat = (nd.z >> sdfk::KD_FEAT_SHIFT) & 3u;
+            const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
+            const float diff1 = val - divlow, diff2 = val - divhigh;
+            const bool lowside = (diff1 + diff2) < 0;
+            const uint32_t r1 = nd.z & ~KD_FEATM, r2 = nd.w;
+            const uint32_t farc = lowside ? r2 : r1;
+            const float pl = lowside ? divhigh : divlow;
+            const float cut = (val - pl) * (val - pl);
+            const float dst = feat == 0 ? d0 : (feat == 1 ? d1 : d2);
+            const float m2 = (mind + cut) - dst;  // nanoflann.hpp:1397
+            stk[(sp * 3 + 0) * stride] = farc | (feat << sdfk::KD_FEAT_SHIFT);
+            stk[(sp * 3 + 1) * stride] = __float_as_uint(m2);
+            stk[(sp * 3 + 2) * stride] = __float_as_uint(cut);
+            ++sp;
+            cur = lowside ? r1 : r2;
+        }
+        {  // leaf (nanoflann.hpp:1350-1367); metric ((0+dx^2)+dy^2)+dz^2 (432-440)
+            const uint32_t left = (cur & sdfk::KD_REF_MASK) >> 4, cnt = cur & 15u;
+            const float* p = M.kd_pts + 3 * (size_t)left;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float dx = qx - p[3 * k], dy = qy - p[3 * k + 1], dz = qz - p[3 * k + 2];
+                const float dist = (dx * dx + dy * dy) + dz * dz;
+                if (dist < best) {  // strict: first visited wins ties (nanoflann.hpp:184)
+                    best = dist;
+                    bestpos = (int)(left + k);
+                }
+            }
+        }
+        for (;;) {
+            if (sp == 0) {
+                best_out = best;
+                return bestpos;
+            }
+            --sp;
+            const uint32_t w0 = stk[(sp * 3 + 0) * stride];
+            const uint32_t feat = (w0 >> sdfk::KD_FEAT_SHIFT) & 3u;
+            const uint32_t ref = w0 & ~KD_FEATM;
+            const float w1 = __uint_as_float(stk[(sp * 3 + 1) * stride]);
+            if (ref == KD_MARK) {  // dists[idx] = dst (nanoflann.hpp:1407)
+                if (feat == 0)
+                    d0 = w1;
+                else if (feat == 1)
+                    d1 = w1;
+                else
+                    d2 = w1;
+                continue;
+            }
+            if (w1 <= best) {  // mindistsq * epsError <= worstDist(), epsError == 1
+                const float cut = __uint_as_float(stk[(sp * 3 + 2) * stride]);
+                float dst;
+                if (feat == 0) {
+                    dst = d0;
+                    d0 = cut;
+                } else if (feat == 1) {
+                    dst = d1;
+                    d1 = cut;
+                } else {
+                    dst = d2;
+                    d2 = cut;
+                }
+                stk[(sp * 3 + 0) * stride] = KD_MARK | (feat << sdfk::KD_FEAT_SHIFT);
+                stk[(sp * 3 + 1) * stride] = __float_as_uint(dst);
+                ++sp;
+                mind = w1;
+                cur = ref;
+                break;
+            }
+        }
+    }
+}
+
+// =========================================================================================
+// ray parity (Impl::_raycast, sdf.cpp:276-328) over the threaded LBVH.
+// Result-relevant per face: closed-interval Overlap of the degenerate query
+// box with the face's rotated AABB (RTree.h:1427-1438) && facing test && bary2d >= 0.
+// The z+ and z- rays share (x,y), the facing dot product and bary2d, so they are one walk.
+// =========================================================================================
+__device__ __forceinline__ void ray_z_pair(const MeshDev& M, V3 q, int& zp, int& zm) {
+    zp = 0;
+    zm = 0;
+    uint32_t i = 0;
+    const uint32_t n = M.n_rnodes;
+    while (i < n) {
+        const float4 a = M.rnodes[2 * (size_t)i];
+        const float4 b = M.rnodes[2 * (size_t)i + 1];
+        const bool hit = !(q.x > a.z || a.x > q.x) && !(q.y > a.w || a.y > q.y);
+        const uint32_t skip = __float_as_uint(b.z), face = __float_as_uint(b.w);
+        if (!hit) {
+            i = skip;
+            continue;
+        }
+        if (face != NOFACE) {
+            const bool okp = !(q.z > b.y || b.x > FLT_MAX);   // box [q.z, FLT_MAX]
+            const bool okm = !(-FLT_MAX > b.y || b.x > q.z);  // box [-FLT_MAX, q.z]
+            const float4 f0 = M.rface[3 * (size_t)face];      // a'.xyz b'.x
+            const float4 f1 = M.rface[3 * (size_t)face + 1];  // b'.yz c'.xy
+            const float4 f2 = M.rface[3 * (size_t)face + 2];  // c'.z n'.xyz
+            const V3 nr = {f2.y, f2.z, f2.w};
+            const V3 dv = sdfk::sub(q, V3{f0.x, f0.y, f0.z});
+            const float s = sdfk::dot(nr, dv) * nr.z;  // sdf.cpp:301-302, ax_idx = 2
+            const bool pos = s > 0.f;                  // z- needs pos, z+ needs !pos
+            if (pos ? okm : okp) {
+                if (sdfk::bary2d_inside(q.x, q.y, f0.x, f0.y, f0.w, f1.x, f1.z, f1.w)) {
+                    if (pos)
+                        zm ^= 1;
+                    else
+                        zp ^= 1;
+                }
+            }
+        }
+        i = i + 1;
+    }
+}
+
+__device__ __forceinline__ int ray_x_pos(const MeshDev& M, V3 q) {
+    int c = 0;
+    uint32_t i = 0;
+    const uint32_t n = M.n_rnodes;
+    while (i < n) {
+        const float4 a = M.rnodes[2 * (size_t)i];
+        const float4 b = M.rnodes[2 * (size_t)i + 1];
+        // box: x in [q.x, FLT_MAX], y and z pinned
+        const bool hit = !(q.y > a.w || a.y > q.y) && !(q.z > b.y || b.x > q.z) &&
+                         !(q.x > a.z || a.x > FLT_MAX);
+        const uint32_t skip = __float_as_uint(b.z), face = __float_as_uint(b.w);
+        if (!hit) {
+            i = skip;
+            continue;
+        }
+        if (face != NOFACE) {
+            const float4 f0 = M.rface[3 * (size_t)face];
+            const float4 f1 = M.rface[3 * (size_t)face + 1];
+            const float4 f2 = M.rface[3 * (size_t)face + 2];
+            const V3 nr = {f2.y, f2.z, f2.w};
+            const V3 dv = sdfk::sub(q, V3{f0.x, f0.y, f0.z});
+            const float s = sdfk::dot(nr, dv) * nr.x;  // ax_idx = 0, ax_inv = false
+            if (!(s > 0.f)) {
+                // segment<2>(1): (y, z)
+                if (sdfk::bary2d_inside(q.y, q.z, f0.y, f0.z, f1.x, f1.y, f1.w, f2.x)) c ^= 1;
+            }
+        }
+        i = i + 1;
+    }
+    return c;
+}
+
+// returns +1 / -1 (sdf.cpp:327); detail (optional) = {z+, z-, x+|-1}
+__device__ __forceinline__ float raycast(const MeshDev& M, V3 p, int* detail) {
+    if (detail) detail[0] = detail[1] = detail[2] = -1;
+    // closed mesh AABB (sdf.cpp:278-283)
+    if (p.x < M.bb[0] || p.x > M.bb[3] || p.y < M.bb[1] || p.y > M.bb[4] || p.z < M.bb[2] ||
+        p.z > M.bb[5])
+        return -1.f;
+    const V3 q = sdfk::mulR(p, M.R);
+    int zp, zm;
+    ray_z_pair(M, q, zp, zm);
+    int result = zp + zm;
+    if (detail) detail[0] = zp, detail[1] = zm;
+    if (result == 1) {  // tiebreaker (sdf.cpp:326)
+        const int xp = ray_x_pos(M, q);
+        if (detail) detail[2] = xp;
+        result += xp;
+    }
+    return result > 1 ? 1.0f : -1.0f;
+}
+
+// =========================================================================================
+// query kernels
+// =========================================================================================
+enum { Q_NN = 0, Q_CONTAINS = 1, Q_SDF = 2, Q_DETAIL = 3 };
+
+// Impl::calc per-point body after the sign (sdf.cpp:112-153)
+template <bool ROBUST, class PTR>
+__device__ __forceinline__ float calc_point(const MeshDev& M, V3 p, bool trunc_aabb, float sign,
+                                            PTR stk, uint32_t stride) {
+    const float DIST_EPS = ROBUST ? 0.f : 1e-5f;
+    float min_dist = FLT_MAX;
+    if (trunc_aabb) {
+        // the `continue` at sdf.cpp:120 only continues the t-loop: execution falls through
+        if (p.x < M.bb[0] || p.x > M.bb[3] || p.y < M.bb[1] || p.y > M.bb[4] || p.z < M.bb[2] ||
+            p.z > M.bb[5])
+            min_dist = -FLT_MAX;
+    }
+    float bestd;
+    const int pos = kd_nearest(M, p.x, p.y, p.z, stk, stride, bestd);
+    V3 avg = {0.f, 0.f, 0.f};
+    V3 vnn = {0.f, 0.f, 0.f};
+    if (pos >= 0) {
+        const int vi = M.kd_vind[pos];
+        vnn = {M.kd_pts[3 * (size_t)pos], M.kd_pts[3 * (size_t)pos + 1], M.kd_pts[3 * (size_t)pos + 2]};
+        const uint32_t fb = M.adj_off[vi], fe = M.adj_off[vi + 1];
+        for (uint32_t k = fb; k < fe; ++k) {
+            const int f = M.adj_faces[k];
+            const float4 g0 = M.geo[4 * (size_t)f];      // a.xyz b.x
+            const float4 g1 = M.geo[4 * (size_t)f + 1];  // b.yz c.xy
+            const float4 g2 = M.geo[4 * (size_t)f + 2];  // c.z n.xyz
+            const float4 g3 = M.geo[4 * (size_t)f + 3];  // area
+            const V3 n = {g2.y, g2.z, g2.w};
+            const float d = sdfk::dist_point2tri(p, V3{g0.x, g0.y, g0.z}, V3{g0.w, g1.x, g1.y},
+                                                 V3{g1.z, g1.w, g2.x}, n, g3.x);
+            if (d < min_dist - DIST_EPS) {  // sdf.cpp:139-144
+                min_dist = d;
+                if (!ROBUST) avg = n;
+            } else if (!ROBUST && d < min_dist + DIST_EPS) {
+                avg = {avg.x + n.x, avg.y + n.y, avg.z + n.z};
+            }
+        }
+    }
+    min_dist = __builtin_sqrtf(min_dist);
+    if (ROBUST) {
+        min_dist *= sign;
+    } else if (pos >= 0 && sdfk::dot(avg, sdfk::sub(p, vnn)) > 0) {
+        min_dist = -min_dist;
+    }
+    return min_dist;
+}
+
+template <int KIND, bool ROBUST, bool GSTACK>
+__global__ __launch_bounds__(QBLOCK) void k_query(MeshDev M, const float* __restrict__ pts,
+                                                  const uint32_t* __restrict__ perm, int64_t n,
+                                                  int trunc_aabb, void* __restrict__ out,
+                                                  uint32_t* gstack, uint32_t depth_cap) {
+    extern __shared__ uint32_t lds[];
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = tid; i < n; i += nthreads) {
+        const int64_t src = perm ? (int64_t)perm[i] : i;
+        const V3 p = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
+        if (KIND == Q_NN) {
+            float bd;
+            int pos;
+            if (GSTACK)
+                pos = kd_nearest(M, p.x, p.y, p.z, gstack + tid, (uint32_t)nthreads, bd);
+            else
+                pos = kd_nearest(M, p.x, p.y, p.z,
+                                 lds + (threadIdx.x >> 6) * depth_cap * 192 + (threadIdx.x & 63),
+                                 64u, bd);
+            ((int32_t*)out)[src] = pos >= 0 ? M.kd_vind[pos] : -1;
+        } else if (KIND == Q_CONTAINS && ROBUST) {
+            ((uint8_t*)out)[src] = raycast(M, p, nullptr) >= 0.0f;  // sdf.cpp:166
+        } else if (KIND == Q_DETAIL) {
+            int d[3];
+            raycast(M, p, d);
+            int32_t* o = (int32_t*)out + 3 * src;
+            o[0] = d[0], o[1] = d[1], o[2] = d[2];
+        } else {
+            float sign = 0.f;
+            if (ROBUST) sign = raycast(M, p, nullptr);  // sdf.cpp:110
+            const bool trunc = (KIND == Q_CONTAINS) ? true : (trunc_aabb != 0);
+            float v;
+            if (GSTACK)
+                v = calc_point<ROBUST>(M, p, trunc, sign, gstack + tid, (uint32_t)nthreads);
+            else
+                v = calc_point<ROBUST>(
+                    M, p, trunc, sign,
+                    lds + (threadIdx.x >> 6) * depth_cap * 192 + (threadIdx.x & 63), 64u);
+            if (KIND == Q_CONTAINS)
+                ((uint8_t*)out)[src] = v >= 0;  // sdf.cpp:171-172 (NaN -> false)
+            else
+                ((float*)out)[src] = v;
+        }
+    }
+}
+
+// =========================================================================================
+// update(): per-face precompute (sdf.cpp:50-70)
+// =========================================================================================
+struct RMat {
+    float m[9];
+};
+
+__global__ void k_face_precompute(const float* __restrict__ verts, const uint32_t* __restrict__ faces,
+                                  uint32_t nf, RMat R, int robust, float4* __restrict__ geo,
+                                  float4* __restrict__ rface, float* __restrict__ fbox,
+                                  float* __restrict__ normals, float* __restrict__ areas) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    const uint32_t ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
+    const V3 a = {verts[3 * (size_t)ia], verts[3 * (size_t)ia + 1], verts[3 * (size_t)ia + 2]};
+    const V3 b = {verts[3 * (size_t)ib], verts[3 * (size_t)ib + 1], verts[3 * (size_t)ib + 2]};
+    const V3 c = {verts[3 * (size_t)ic], verts[3 * (size_t)ic + 1], verts[3 * (size_t)ic + 2]};
+    V3 n = sdfk::cross(sdfk::sub(b, a), sdfk::sub(c, a));  // sdf.hpp:75-81
+    const float area = __builtin_sqrtf(sdfk::sqnorm(n));     // sdf.cpp:68
+    n = {n.x / area, n.y / area, n.z / area};                 // sdf.cpp:69
+    areas[f] = area;
+    normals[3 * f] = n.x, normals[3 * f + 1] = n.y, normals[3 * f + 2] = n.z;
+    geo[4 * (size_t)f] = make_float4(a.x, a.y, a.z, b.x);
+    geo[4 * (size_t)f + 1] = make_float4(b.y, b.z, c.x, c.y);
+    geo[4 * (size_t)f + 2] = make_float4(c.z, n.x, n.y, n.z);
+    geo[4 * (size_t)f + 3] = make_float4(area, 0.f, 0.f, 0.f);
+    if (robust) {
+        const V3 ra = sdfk::mulR(a, R.m), rb = sdfk::mulR(b, R.m), rc = sdfk::mulR(c, R.m);
+        const V3 rn = sdfk::mulR(n, R.m);  // sdf.cpp:299-300
+        V3 mn = ra, mx = ra;               // sdf.cpp:54-63
+        mn = {sdfk::stdmin(mn.x, rb.x), sdfk::stdmin(mn.y, rb.y), sdfk::stdmin(mn.z, rb.z)};
+        mn = {sdfk::stdmin(mn.x, rc.x), sdfk::stdmin(mn.y, rc.y), sdfk::stdmin(mn.z, rc.z)};
+        mx = {sdfk::stdmax(mx.x, rb.x), sdfk::stdmax(mx.y, rb.y), sdfk::stdmax(mx.z, rb.z)};
+        mx = {sdfk::stdmax(mx.x, rc.x), sdfk::stdmax(mx.y, rc.y), sdfk::stdmax(mx.z, rc.z)};
+        rface[3 * (size_t)f] = make_float4(ra.x, ra.y, ra.z, rb.x);
+        rface[3 * (size_t)f + 1] = make_float4(rb.y, rb.z, rc.x, rc.y);
+        rface[3 * (size_t)f + 2] = make_float4(rc.z, rn.x, rn.y, rn.z);
+        fbox[6 * (size_t)f] = mn.x, fbox[6 * (size_t)f + 1] = mn.y, fbox[6 * (size_t)f + 2] = mn.z;
+        fbox[6 * (size_t)f + 3] = mx.x, fbox[6 * (size_t)f + 4] = mx.y, fbox[6 * (size_t)f + 5] = mx.z;
+    }
+}
+
+// =========================================================================================
+// LDS radix sort of (u32 key, u32 value) pairs, 8 bits per pass, stable.
+//   k_rs_hist   : per-tile digit histogram (LDS atomics) -> hist[digit][tile]
+//   scan        : exclusive scan of hist (digit-major), hierarchical
+//   k_rs_scatter: per 64-key wave chunk, ballot "match" masks give each key its stable rank
+//                 among equal digits; chunk bases are scanned in LDS per digit
+// =========================================================================================
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 2048
+constexpr int RS_CHUNKS = RS_TILE / 64;         // 32
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t* __restrict__ keys, uint32_t n,
+                                                        int shift, uint32_t* __restrict__ hist,
+                                                        uint32_t ntiles) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// block-level exclusive scan of 2048 entries per block; block totals to sums[]
+__global__ __launch_bounds__(256) void k_scan_block(uint32_t* __restrict__ data, uint32_t n,
+                                                    uint32_t* __restrict__ sums) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t base = blockIdx.x * 2048u + threadIdx.x * 8u;
+    uint32_t v[8], t = 0;
+    for (int k = 0; k < 8; ++k) {
+        v[k] = (base + k < n) ? data[base + k] : 0u;
+        t += v[k];
+    }
+    // inclusive scan of t across the block
+    uint32_t x = t;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    uint32_t run = woff + x - t;
+    for (int k = 0; k < 8; ++k) {
+        if (base + k < n) data[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 255 && sums) sums[blockIdx.x] = woff + x;
+}
+__global__ void k_scan_add(uint32_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ sums) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) data[i] += sums[i / 2048u];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+    const uint32_t* __restrict__ hist, uint32_t ntiles, int vals_iota) {
+    __shared__ uint32_t cnt[RS_CHUNKS * 256];  // 32 KB
+    for (int k = threadIdx.x; k < RS_CHUNKS * 256; k += RS_THREADS) cnt[k] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * RS_TILE;
+    uint32_t key[RS_ITEMS], rank[RS_ITEMS];
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // wave w owns chunks w*8 .. w*8+7 (keys [chunk*64, chunk*64+64) of the tile)
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int chunk = w * RS_ITEMS + k;
+        const uint32_t i = base + chunk * 64 + lane;
+        const bool valid = i < n;
+        key[k] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        const uint32_t dg = (key[k] >> shift) & 255u;
+        unsigned long long m = __ballot(valid);
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bl = __ballot((dg >> b) & 1u);
+            m &= ((dg >> b) & 1u) ? bl : ~bl;
+        }
+        rank[k] = __popcll(m & lt);
+        if (valid && rank[k] == 0) cnt[chunk * 256 + dg] = __popcll(m);
+    }
+    __syncthreads();
+    {  // per digit: exclusive scan over chunks, seeded with the global base of this tile
+        const uint32_t dg = threadIdx.x;
+        uint32_t run = hist[dg * ntiles + blockIdx.x];
+        for (int c = 0; c < RS_CHUNKS; ++c) {
+            const uint32_t t = cnt[c * 256 + dg];
+            cnt[c * 256 + dg] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int chunk = w * RS_ITEMS + k;
+        const uint32_t i = base + chunk * 64 + lane;
+        if (i < n) {
+            const uint32_t dg = (key[k] >> shift) & 255u;
+            const uint32_t dst = cnt[chunk * 256 + dg] + rank[k];
+            keys_out[dst] = key[k];
+            vals_out[dst] = vals_iota ? i : vals_in[i];
+        }
+    }
+}
+
+struct RadixSorter {
+    uint32_t* keys_alt = nullptr;
+    uint32_t* vals_alt = nullptr;
+    uint32_t* hist = nullptr;
+    uint32_t* sums1 = nullptr;
+    uint32_t* sums2 = nullptr;
+    uint32_t cap = 0;
+
+    int reserve(uint32_t n) {
+        if (n <= cap) return 0;
+        release();
+        const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+        const uint32_t nh = 256u * ntiles;
+        const uint32_t n1 = (nh + 2047) / 2048, n2 = (n1 + 2047) / 2048;
+        HIPC(hipMalloc(&keys_alt, sizeof(uint32_t) * (size_t)n));
+        HIPC(hipMalloc(&vals_alt, sizeof(uint32_t) * (size_t)n));
+        HIPC(hipMalloc(&hist, sizeof(uint32_t) * (size_t)nh));
+        HIPC(hipMalloc(&sums1, sizeof(uint32_t) * (size_t)(n1 + 1)));
+        HIPC(hipMalloc(&sums2, sizeof(uint32_t) * (size_t)(n2 + 1)));
+        cap = n;
+        return 0;
+    }
+    void release() {
+        void* ps[] = {keys_alt, vals_alt, hist, sums1, sums2};
+        for (void* p : ps)
+            if (p) (void)hipFree(p);
+        keys_alt = vals_alt = hist = sums1 = sums2 = nullptr;
+        cap = 0;
+    }
+    // sorts (keys, vals) ascending by the low `bits` bits of keys; the result lands back in
+    // keys/vals (an even number of passes).  iota = 1: input values are taken as 0..n-1.
+    int sort(uint32_t* keys, uint32_t* vals, uint32_t n, int bits, int iota, hipStream_t s) {
+        if (n == 0) return 0;
+        if (int rc = reserve(n)) return rc;
+        int passes = (bits + 7) / 8;
+        if (passes & 1) ++passes;
+        const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+        const uint32_t nh = 256u * ntiles;
+        const uint32_t n1 = (nh + 2047) / 2048, n2 = (n1 + 2047) / 2048;
+        if (n2 > 2048) return fail(SDFHIP_E_INVALID, "radix sort: too many keys (%u)", n);
+        uint32_t *ki = keys, *vi = vals, *ko = keys_alt, *vo = vals_alt;
+        for (int p = 0; p < passes; ++p) {
+            const int shift = 8 * p;
+            k_rs_hist<<<ntiles, RS_THREADS, 0, s>>>(ki, n, shift, hist, ntiles);
+            k_scan_block<<<n1, 256, 0, s>>>(hist, nh, sums1);
+            if (n1 > 1) {
+                k_scan_block<<<n2, 256, 0, s>>>(sums1, n1, sums2);
+                if (n2 > 1) {
+                    k_scan_block<<<1, 256, 0, s>>>(sums2, n2, nullptr);
+                    k_scan_add<<<(n1 + 255) / 256, 256, 0, s>>>(sums1, n1, sums2);
+                }
+                k_scan_add<<<(nh + 255) / 256, 256, 0, s>>>(hist, nh, sums1);
+            }
+            k_rs_scatter<<<ntiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, hist, ntiles,
+                                                       (p == 0 && iota) ? 1 : 0);
+            uint32_t* t = ki;
+            ki = ko, ko = t;
+            t = vi;
+            vi = vo, vo = t;
+        }
+        HIPC(hipGetLastError());
+        return 0;
+    }
+};
+
+// =========================================================================================
+// Morton codes
+// =========================================================================================
+__device__ __forceinline__ uint32_t expand10(uint32_t v) {
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton30(float x, float y, float z, const float* lo, const float* inv) {
+    float fx = (x - lo[0]) * inv[0], fy = (y - lo[1]) * inv[1], fz = (z - lo[2]) * inv[2];
+    fx = fminf(fmaxf(fx, 0.f), 1023.f);
+    fy = fminf(fmaxf(fy, 0.f), 1023.f);
+    fz = fminf(fmaxf(fz, 0.f), 1023.f);
+    return (expand10((uint32_t)fx) << 2) | (expand10((uint32_t)fy) << 1) | expand10((uint32_t)fz);
+}
+
+struct Bounds {
+    float lo[3], inv[3];
+};
+
+__global__ void k_face_morton(const float4* __restrict__ geo, uint32_t nf, Bounds B,
+                              uint32_t* __restrict__ keys) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    const float4 g0 = geo[4 * (size_t)f], g1 = geo[4 * (size_t)f + 1], g2 = geo[4 * (size_t)f + 2];
+    const float cx = (g0.x + g0.w + g1.z) * (1.f / 3.f), cy = (g0.y + g1.x + g1.w) * (1.f / 3.f),
+                cz = (g0.z + g1.y + g2.x) * (1.f / 3.f);
+    keys[f] = morton30(cx, cy, cz, B.lo, B.inv);
+}
+
+// query chunk bounds: block min/max -> atomics on an order-preserving uint encoding
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+__global__ void k_bounds_init(uint32_t* b) {
+    if (threadIdx.x < 3) b[threadIdx.x] = 0xFFFFFFFFu;
+    else if (threadIdx.x < 6) b[threadIdx.x] = 0u;
+}
+__global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, int64_t n, uint32_t* b) {
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        for (int d = 0; d < 3; ++d) {
+            const float v = pts[3 * i + d];
+            if (v == v && fabsf(v) <= FLT_MAX) {
+                lo[d] = fminf(lo[d], v);
+                hi[d] = fmaxf(hi[d], v);
+            }
+        }
+    }
+    for (int d = 0; d < 3; ++d) {
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int d = 0; d < 3; ++d) {
+            atomicMin(&b[d], f2ord(lo[d]));
+            atomicMax(&b[3 + d], f2ord(hi[d]));
+        }
+    }
+}
+__global__ void k_query_morton(const float* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ b,
+                               uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float lo[3], inv[3];
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = ord2f(b[d]);
+        const float ext = ord2f(b[3 + d]) - lo[d];
+        inv[d] = ext > 0.f ? 1024.f / ext : 0.f;
+    }
+    keys[i] = morton30(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], lo, inv);
+}
+
+// =========================================================================================
+// LBVH topology (Karras 2012) over Morton-sorted faces, then a threaded pre-order layout.
+// Internal node i in [0, n-2], leaf p in [0, n-1] (sorted position).
+//   pre-order index of a node = 2 * lo + (#ancestors entered through their LEFT child)
+//   skip = index + 2 * (#leaves below) - 1
+// =========================================================================================
+struct LbvhTopo {
+    uint32_t* lo;       // [n-1] first leaf of internal node
+    uint32_t* hi;       // [n-1] last leaf
+    uint32_t* split;    // [n-1] gamma: left child covers [lo, gamma]
+    int32_t* parentI;   // [n-1] parent of internal node (-1 root)
+    int32_t* parentL;   // [n]   parent of leaf
+    uint32_t* posI;     // [n-1] pre-order index
+    uint32_t* posL;     // [n]
+    uint32_t* depthI;   // [n-1] #ancestors
+};
+
+__device__ __forceinline__ int lbvh_delta(const uint32_t* __restrict__ codes, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = ((unsigned long long)codes[i] << 32) | (uint32_t)i;
+    const unsigned long long b = ((unsigned long long)codes[j] << 32) | (uint32_t)j;
+    return __clzll((long long)(a ^ b));
+}
+
+__global__ void k_lbvh_karras(const uint32_t* __restrict__ codes, int n, LbvhTopo T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (lbvh_delta(codes, n, i, i + 1) - lbvh_delta(codes, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(codes, n, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(codes, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (lbvh_delta(codes, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = lbvh_delta(codes, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (lbvh_delta(codes, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    T.lo[i] = lo, T.hi[i] = hi, T.split[i] = gamma;
+    if (lo == gamma)
+        T.parentL[gamma] = i;
+    else
+        T.parentI[gamma] = i;
+    if (hi == gamma + 1)
+        T.parentL[gamma + 1] = i;
+    else
+        T.parentI[gamma + 1] = i;
+    if (i == 0) T.parentI[0] = -1;
+}
+
+// one thread per node (internal first, then leaves): walk to the root
+__global__ void k_lbvh_layout(int n, LbvhTopo T, const uint32_t* __restrict__ sorted_face,
+                              float4* __restrict__ rnodes, uint32_t* __restrict__ maxdepth) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n - 1) return;
+    const bool leaf = t >= n - 1;
+    const int id = leaf ? t - (n - 1) : t;
+    uint32_t mylo = leaf ? (uint32_t)id : T.lo[id];
+    const uint32_t lo0 = mylo, nleaves = leaf ? 1u : (T.hi[id] - T.lo[id] + 1u);
+    int par = leaf ? T.parentL[id] : T.parentI[id];
+    if (n == 1) par = -1;
+    uint32_t lefts = 0, depth = 0;
+    while (par >= 0) {
+        const uint32_t plo = T.lo[par];
+        lefts += (mylo == plo) ? 1u : 0u;
+        ++depth;
+        mylo = plo;
+        par = T.parentI[par];
+    }
+    const uint32_t pos = 2u * lo0 + lefts;
+    const uint32_t skip = pos + 2u * nleaves - 1u;
+    if (leaf) {
+        T.posL[id] = pos;
+        // box is filled by k_lbvh_leaf_boxes
+        rnodes[2 * (size_t)pos + 1] = make_float4(0.f, 0.f, __uint_as_float(skip),
+                                                  __uint_as_float(sorted_face[id]));
+    } else {
+        T.posI[id] = pos;
+        T.depthI[id] = depth;
+        rnodes[2 * (size_t)pos + 1] = make_float4(0.f, 0.f, __uint_as_float(skip), __uint_as_float(NOFACE));
+        atomicMax(maxdepth, depth);
+    }
+}
+
+__global__ void k_lbvh_leaf_boxes(int n, const uint32_t* __restrict__ posL,
+                                  const uint32_t* __restrict__ sorted_face,
+                                  const float* __restrict__ fbox, float4* __restrict__ rnodes) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t f = sorted_face[p], pos = posL[p];
+    const float* b = fbox + 6 * (size_t)f;
+    rnodes[2 * (size_t)pos] = make_float4(b[0], b[1], b[3], b[4]);
+    float4 w = rnodes[2 * (size_t)pos + 1];
+    w.x = b[2], w.y = b[5];
+    rnodes[2 * (size_t)pos + 1] = w;
+}
+
+// one launch per depth, deepest first: children are complete (previous launch / leaves)
+__global__ void k_lbvh_fit(int n, LbvhTopo T, uint32_t depth, float4* __restrict__ rnodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || T.depthI[i] != depth) return;
+    const uint32_t pos = T.posI[i];
+    const uint32_t c1 = pos + 1, c2 = pos + 2u * (T.split[i] - T.lo[i] + 1u);
+    const float4 a1 = rnodes[2 * (size_t)c1], b1 = rnodes[2 * (size_t)c1 + 1];
+    const float4 a2 = rnodes[2 * (size_t)c2], b2 = rnodes[2 * (size_t)c2 + 1];
+    rnodes[2 * (size_t)pos] =
+        make_float4(fminf(a1.x, a2.x), fminf(a1.y, a2.y), fmaxf(a1.z, a2.z), fmaxf(a1.w, a2.w));
+    float4 w = rnodes[2 * (size_t)pos + 1];
+    w.x = fminf(b1.x, b2.x), w.y = fmaxf(b1.y, b2.y);
+    rnodes[2 * (size_t)pos + 1] = w;
+}
+
+// =========================================================================================
+// handle
+// =========================================================================================
+struct sdfhip_ctx {
+    int device = 0;
+    bool robust = true, own = false;
+    uint32_t nv = 0, nf = 0;
+    const float* h_verts = nullptr;
+    const uint32_t* h_faces = nullptr;
+    std::vector<float> owned_verts;
+    std::vector<uint32_t> owned_faces;
+    // host-side products
+    std::vector<uint32_t> adj_off;
+    std::vector<int32_t> adj_faces;
+    std::vector<float> h_normals, h_areas;
+    bool h_face_valid = false;
+    float aabb[6] = {0, 0, 0, 0, 0, 0};
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    bool R_pinned = false;
+    sdfk::KdHost kd;
+    // device
+    float* d_verts = nullptr;
+    uint32_t* d_faces = nullptr;
+    uint4* d_kd_nodes = nullptr;
+    float* d_kd_pts = nullptr;
+    int32_t* d_kd_vind = nullptr;
+    size_t kd_nodes_cap = 0;
+    uint32_t* d_adj_off = nullptr;
+    int32_t* d_adj_faces = nullptr;
+    float4* d_geo = nullptr;
+    float4* d_rface = nullptr;
+    float* d_fbox = nullptr;
+    float* d_normals = nullptr;
+    float* d_areas = nullptr;
+    float4* d_rnodes = nullptr;
+    uint32_t n_rnodes = 0;
+    uint32_t* d_sorted_face = nullptr;
+    uint32_t* d_codes = nullptr;
+    uint32_t* d_maxdepth = nullptr;
+    LbvhTopo topo{};
+    uint32_t bvh_depth = 0;
+    bool topo_built = false;
+    RadixSorter sorter;
+    // query workspace
+    uint32_t* d_qkeys = nullptr;
+    uint32_t* d_qperm = nullptr;
+    uint32_t* d_qbounds = nullptr;
+    uint32_t* d_gstack = nullptr;
+    size_t gstack_words = 0;
+    float* d_stage_pts = nullptr;
+    void* d_stage_out = nullptr;
+    int64_t q_cap = 0;
+    // options
+    int64_t opt_sort = 1, opt_sort_min = 8192, opt_chunk = 1 << 24;
+    hipStream_t stream = nullptr;  // internal stream for create/update and host entry points
+    std::mutex mu;
+    std::mt19937 rng;
+    float last_update_ms = 0.f, last_kd_ms = 0.f;
+};
+
+namespace {
+
+struct DevGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <class T>
+int dalloc(T** p, size_t count) {
+    if (*p) {
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    if (count == 0) count = 1;
+    HIPC(hipMalloc((void**)p, sizeof(T) * count));
+    return 0;
+}
+
+void draw_rotation(sdfhip_ctx* h) {
+    // sdf.cpp:43-48: unit quaternion from 4 N(0,1) draws, Eigen toRotationMatrix term order
+    std::normal_distribution<float> g(0.0f, 1.0f);
+    float w = g(h->rng), x = g(h->rng), y = g(h->rng), z = g(h->rng);
+    float nrm = std::sqrt(w * w + x * x + y * y + z * z);
+    if (!(nrm > 0.f)) w = 1.f, x = y = z = 0.f, nrm = 1.f;
+    w /= nrm, x /= nrm, y /= nrm, z /= nrm;
+    const float tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w;
+    const float txx = tx * x, txy = ty * x, txz = tz * x;
+    const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    float* R = h->R;
+    R[0] = 1 - (tyy + tzz), R[1] = txy - twz, R[2] = txz + twy;
+    R[3] = txy + twz, R[4] = 1 - (txx + tzz), R[5] = tyz - twx;
+    R[6] = txz - twy, R[7] = tyz + twx, R[8] = 1 - (txx + tyy);
+}
+
+int build_topology(sdfhip_ctx* h) {
+    const uint32_t n = h->nf;
+    hipStream_t s = h->stream;
+    if (n == 0) {
+        h->n_rnodes = 0;
+        h->topo_built = true;
+        return 0;
+    }
+    Bounds B;
+    for (int d = 0; d < 3; ++d) {
+        B.lo[d] = h->aabb[d];
+        const float ext = h->aabb[d + 3] - h->aabb[d];
+        B.inv[d] = ext > 0.f ? 1024.f / ext : 0.f;
+    }
+    k_face_morton<<<(n + 255) / 256, 256, 0, s>>>(h->d_geo, n, B, h->d_codes);
+    if (int rc = h->sorter.sort(h->d_codes, h->d_sorted_face, n, 30, 1, s)) return rc;
+    HIPC(hipMemsetAsync(h->d_maxdepth, 0, sizeof(uint32_t), s));
+    if (n > 1) k_lbvh_karras<<<(n - 1 + 255) / 256, 256, 0, s>>>(h->d_codes, (int)n, h->topo);
+    k_lbvh_layout<<<(2 * n - 1 + 255) / 256, 256, 0, s>>>((int)n, h->topo, h->d_sorted_face,
+                                                          h->d_rnodes, h->d_maxdepth);
+    HIPC(hipMemcpyAsync(&h->bvh_depth, h->d_maxdepth, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    h->n_rnodes = 2 * n - 1;
+    h->topo_built = true;
+    return 0;
+}
+
+int refit(sdfhip_ctx* h) {
+    const uint32_t n = h->nf;
+    if (n == 0) return 0;
+    hipStream_t s = h->stream;
+    k_lbvh_leaf_boxes<<<(n + 255) / 256, 256, 0, s>>>((int)n, h->topo.posL, h->d_sorted_face,
+                                                      h->d_fbox, h->d_rnodes);
+    if (n > 1)
+        for (int d = (int)h->bvh_depth; d >= 0; --d)
+            k_lbvh_fit<<<(n - 1 + 255) / 256, 256, 0, s>>>((int)n, h->topo, (uint32_t)d, h->d_rnodes);
+    HIPC(hipGetLastError());
+    return 0;
+}
+
+// rotation-dependent + vertex-dependent precompute; verts must already be in d_verts
+int update_device_side(sdfhip_ctx* h) {
+    hipStream_t s = h->stream;
+    RMat R;
+    std::memcpy(R.m, h->R, sizeof(R.m));
+    if (h->nf)
+        k_face_precompute<<<(h->nf + 255) / 256, 256, 0, s>>>(h->d_verts, h->d_faces, h->nf, R,
+                                                               h->robust ? 1 : 0, h->d_geo, h->d_rface,
+                                                               h->d_fbox, h->d_normals, h->d_areas);
+    HIPC(hipGetLastError());
+    h->h_face_valid = false;
+    if (h->robust) {
+        if (!h->topo_built)
+            if (int rc = build_topology(h)) return rc;
+        if (int rc = refit(h)) return rc;
+    }
+    return 0;
+}
+
+int do_update(sdfhip_ctx* h, bool draw_R) {
+    auto t0 = std::chrono::steady_clock::now();
+    hipStream_t s = h->stream;
+    // strict kd-tree on the host (sdf.cpp:32 kd_tree.rebuild())
+    h->kd.build(h->h_verts, h->nv);
+    auto t1 = std::chrono::steady_clock::now();
+    h->last_kd_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    std::memcpy(h->aabb, h->kd.bbox, sizeof(h->aabb));  // sdf.cpp:36-37
+    if (h->kd.nodes.size() >= (size_t)KD_MARK)
+        return fail(SDFHIP_E_INVALID, "kd-tree too large");
+    if (h->kd.nodes.size() > h->kd_nodes_cap) {
+        if (int rc = dalloc(&h->d_kd_nodes, h->kd.nodes.size())) return rc;
+        h->kd_nodes_cap = h->kd.nodes.size();
+    }
+    // points in tree order
+    std::vector<float> perm_pts(3 * (size_t)h->nv);
+    for (uint32_t i = 0; i < h->nv; ++i) {
+        const float* src = h->h_verts + 3 * (size_t)h->kd.vind[i];
+        perm_pts[3 * (size_t)i] = src[0], perm_pts[3 * (size_t)i + 1] = src[1];
+        perm_pts[3 * (size_t)i + 2] = src[2];
+    }
+    if (h->nv) {
+        HIPC(hipMemcpyAsync(h->d_verts, h->h_verts, sizeof(float) * 3 * (size_t)h->nv,
+                            hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(h->d_kd_pts, perm_pts.data(), sizeof(float) * 3 * (size_t)h->nv,
+                            hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(h->d_kd_vind, h->kd.vind.data(), sizeof(int32_t) * (size_t)h->nv,
+                            hipMemcpyHostToDevice, s));
+    }
+    if (!h->kd.nodes.empty())
+        HIPC(hipMemcpyAsync(h->d_kd_nodes, h->kd.nodes.data(), sizeof(uint4) * h->kd.nodes.size(),
+                            hipMemcpyHostToDevice, s));
+    HIPC(hipStreamSynchronize(s));  // perm_pts is pageable and about to go out of scope
+    if (h->robust && draw_R && !h->R_pinned) draw_rotation(h);
+    if (int rc = update_device_side(h)) return rc;
+    HIPC(hipStreamSynchronize(s));
+    h->last_update_ms =
+        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+MeshDev mesh_view(const sdfhip_ctx* h) {
+    MeshDev M;
+    M.kd_nodes = h->d_kd_nodes;
+    M.kd_pts = h->d_kd_pts;
+    M.kd_vind = h->d_kd_vind;
+    M.kd_root = h->kd.root_ref;
+    for (int d = 0; d < 6; ++d) M.bb[d] = h->aabb[d];
+    M.adj_off = h->d_adj_off;
+    M.adj_faces = h->d_adj_faces;
+    M.geo = h->d_geo;
+    M.rnodes = h->d_rnodes;
+    M.n_rnodes = h->robust ? h->n_rnodes : 0;
+    M.rface = h->d_rface;
+    for (int d = 0; d < 9; ++d) M.R[d] = h->R[d];
+    return M;
+}
+
+template <int KIND, bool ROBUST>
+int launch_query(sdfhip_ctx* h, const MeshDev& M, const float* d_pts, const uint32_t* perm, int64_t n,
+                 int trunc, void* d_out, hipStream_t s) {
+    const bool needs_kd = !(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST));
+    const uint32_t depth = (uint32_t)(h->kd.depth > 0 ? h->kd.depth : 1);
+    const int64_t blocks_full = (n + QBLOCK - 1) / QBLOCK;
+    if (needs_kd && depth > (uint32_t)LDS_DEPTH_MAX) {
+        const int64_t blocks = blocks_full < 4096 ? blocks_full : 4096;
+        const size_t words = (size_t)blocks * QBLOCK * depth * 3;
+        if (words > h->gstack_words) {
+            if (int rc = dalloc(&h->d_gstack, words)) return rc;
+            h->gstack_words = words;
+        }
+        k_query<KIND, ROBUST, true><<<(uint32_t)blocks, QBLOCK, 0, s>>>(M, d_pts, perm, n, trunc, d_out,
+                                                                        h->d_gstack, depth);
+    } else {
+        const size_t lds = needs_kd ? (size_t)(QBLOCK / 64) * depth * 192 * sizeof(uint32_t) : 0;
+        const int64_t blocks = blocks_full < 0x7FFFFFFF ? blocks_full : 0x7FFFFFFF;
+        k_query<KIND, ROBUST, false><<<(uint32_t)blocks, QBLOCK, lds, s>>>(M, d_pts, perm, n, trunc,
+                                                                           d_out, nullptr, depth);
+    }
+    HIPC(hipGetLastError());
+    return 0;
+}
+
+int reserve_query_ws(sdfhip_ctx* h, int64_t n) {
+    if (n <= h->q_cap) return 0;
+    if (int rc = dalloc(&h->d_qkeys, (size_t)n)) return rc;
+    if (int rc = dalloc(&h->d_qperm, (size_t)n)) return rc;
+    if (!h->d_qbounds)
+        if (int rc = dalloc(&h->d_qbounds, 8)) return rc;
+    h->q_cap = n;
+    return 0;
+}
+
+// the whole query path on device pointers; out element size depends on kind
+int run_query(sdfhip_ctx* h, int kind, const float* d_pts, int64_t n, int trunc, void* d_out,
+              hipStream_t s) {
+    if (n < 0) return fail(SDFHIP_E_INVALID, "negative point count");
+    if (n == 0) return 0;
+    if (!d_pts || !d_out) return fail(SDFHIP_E_INVALID, "null points/output pointer");
+    const MeshDev M = mesh_view(h);
+    const size_t osz = kind == Q_CONTAINS ? 1 : (kind == Q_DETAIL ? 12 : 4);
+    const int64_t chunk = h->opt_chunk > 0 ? h->opt_chunk : (1 << 24);
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = (n - off) < chunk ? (n - off) : chunk;
+        const float* p = d_pts + 3 * off;
+        void* o = (char*)d_out + osz * (size_t)off;
+        const uint32_t* perm = nullptr;
+        if (h->opt_sort && m >= h->opt_sort_min) {
+            if (int rc = reserve_query_ws(h, m)) return rc;
+            k_bounds_init<<<1, 64, 0, s>>>(h->d_qbounds);
+            const int nb = (int)((m + 255) / 256 < 2048 ? (m + 255) / 256 : 2048);
+            k_bounds<<<nb, 256, 0, s>>>(p, m, h->d_qbounds);
+            k_query_morton<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(p, (uint32_t)m, h->d_qbounds,
+                                                                       h->d_qkeys);
+            if (int rc = h->sorter.sort(h->d_qkeys, h->d_qperm, (uint32_t)m, 30, 1, s)) return rc;
+            perm = h->d_qperm;
+        }
+        int rc = 0;
+        if (h->robust) {
+            switch (kind) {
+                case Q_NN: rc = launch_query<Q_NN, true>(h, M, p, perm, m, trunc, o, s); break;
+                case Q_CONTAINS: rc = launch_query<Q_CONTAINS, true>(h, M, p, perm, m, trunc, o, s); break;
+                case Q_SDF: rc = launch_query<Q_SDF, true>(h, M, p, perm, m, trunc, o, s); break;
+                case Q_DETAIL: rc = launch_query<Q_DETAIL, true>(h, M, p, perm, m, trunc, o, s); break;
+            }
+        } else {
+            switch (kind) {
+                case Q_NN: rc = launch_query<Q_NN, false>(h, M, p, perm, m, trunc, o, s); break;
+                case Q_CONTAINS: rc = launch_query<Q_CONTAINS, false>(h, M, p, perm, m, trunc, o, s); break;
+                case Q_SDF: rc = launch_query<Q_SDF, false>(h, M, p, perm, m, trunc, o, s); break;
+                default: return fail(SDFHIP_E_STATE, "raycast detail needs a robust handle");
+            }
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// host-pointer entry: stage through device buffers in chunks
+int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int trunc, void* out) {
+    if (!h) return fail(SDFHIP_E_INVALID, "null handle");
+    if (n < 0) return fail(SDFHIP_E_INVALID, "negative point count");
+    if (n == 0) return 0;
+    if (!pts || !out) return fail(SDFHIP_E_INVALID, "null points/output pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DevGuard g(h->device);
+    if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
+    const size_t osz = kind == Q_CONTAINS ? 1 : (kind == Q_DETAIL ? 12 : 4);
+    const int64_t chunk = 1 << 22;
+    const int64_t cap = n < chunk ? n : chunk;
+    float* d_p = nullptr;
+    void* d_o = nullptr;
+    HIPC(hipMalloc((void**)&d_p, sizeof(float) * 3 * (size_t)cap));
+    if (hipMalloc(&d_o, osz * (size_t)cap) != hipSuccess) {
+        (void)hipFree(d_p);
+        return fail(SDFHIP_E_NOMEM, "hipMalloc failed for the output staging buffer");
+    }
+    int rc = 0;
+    for (int64_t off = 0; off < n && !rc; off += cap) {
+        const int64_t m = (n - off) < cap ? (n - off) : cap;
+        hipError_t e = hipMemcpyAsync(d_p, pts + 3 * off, sizeof(float) * 3 * (size_t)m,
+                                      hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            rc = run_query(h, kind, d_p, m, trunc, d_o, h->stream);
+            if (!rc)
+                e = hipMemcpyAsync((char*)out + osz * (size_t)off, d_o, osz * (size_t)m,
+                                   hipMemcpyDeviceToHost, h->stream);
+        }
+        if (!rc && e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (!rc && e != hipSuccess) rc = fail(SDFHIP_E_HIP, "HIP error in query: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_p);
+    (void)hipFree(d_o);
+    return rc;
+}
+
+int run_query_dev(sdfhip_ctx* h, int kind, const float* d_pts, int64_t n, int trunc, void* d_out,
+                  void* stream) {
+    if (!h) return fail(SDFHIP_E_INVALID, "null handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DevGuard g(h->device);
+    if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
+    return run_query(h, kind, d_pts, n, trunc, d_out, (hipStream_t)stream);
+}
+
+int fetch_face_host(sdfhip_ctx* h) {
+    if (h->h_face_valid) return 0;
+    DevGuard g(h->device);
+    h->h_normals.resize(3 * (size_t)h->nf);
+    h->h_areas.resize(h->nf);
+    if (h->nf) {
+        HIPC(hipMemcpy(h->h_normals.data(), h->d_normals, sizeof(float) * 3 * (size_t)h->nf,
+                       hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(h->h_areas.data(), h->d_areas, sizeof(float) * (size_t)h->nf, hipMemcpyDeviceToHost));
+    }
+    h->h_face_valid = true;
+    return 0;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char* sdfhip_last_error(void) { return g_err.c_str(); }
+const char* sdfhip_version(void) { return "sdfhip 0.1 (gfx950)"; }
+
+int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, int robust,
+                  int copy, int device, sdfhip_t** out) {
+    if (!out) return fail(SDFHIP_E_INVALID, "out is null");
+    *out = nullptr;
+    if ((nv && !verts) || (nf && !faces)) return fail(SDFHIP_E_INVALID, "null verts/faces");
+    if (nv >= sdfk::KD_MAX_POINTS) return fail(SDFHIP_E_INVALID, "too many vertices (max %u)", sdfk::KD_MAX_POINTS);
+    if (nf >= (1u << 30)) return fail(SDFHIP_E_INVALID, "too many faces");
+    for (size_t i = 0; i < 3 * (size_t)nf; ++i)
+        if (faces[i] >= nv) return fail(SDFHIP_E_INVALID, "face index %u out of range at %zu", faces[i], i);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(SDFHIP_E_NODEVICE, "no HIP device available (there is no CPU fallback)");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= ndev) return fail(SDFHIP_E_INVALID, "device %d out of range (%d devices)", device, ndev);
+    DevGuard g(device);
+    if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", device);
+
+    sdfhip_ctx* h = new sdfhip_ctx();
+    h->device = device;
+    h->robust = robust != 0;
+    h->own = copy != 0;
+    h->nv = nv, h->nf = nf;
+    if (copy) {
+        h->owned_verts.assign(verts, verts + 3 * (size_t)nv);
+        h->owned_faces.assign(faces, faces + 3 * (size_t)nf);
+        h->h_verts = h->owned_verts.data();
+        h->h_faces = h->owned_faces.data();
+    } else {
+        h->h_verts = verts, h->h_faces = faces;
+    }
+    {  // util.cpp:32-40
+        std::random_device rd;
+        h->rng.seed(rd() ^ (unsigned)std::chrono::high_resolution_clock::now().time_since_epoch().count());
+    }
+    // adjacency (sdf.cpp:22-26): CSR, ascending face id per vertex
+    h->adj_off.assign((size_t)nv + 1, 0);
+    for (size_t i = 0; i < 3 * (size_t)nf; ++i) h->adj_off[h->h_faces[i] + 1]++;
+    for (uint32_t v = 0; v < nv; ++v) h->adj_off[v + 1] += h->adj_off[v];
+    h->adj_faces.resize(3 * (size_t)nf);
+    {
+        std::vector<uint32_t> fill(h->adj_off.begin(), h->adj_off.end() - 1);
+        for (uint32_t f = 0; f < nf; ++f)
+            for (int j = 0; j < 3; ++j) h->adj_faces[fill[h->h_faces[3 * (size_t)f + j]]++] = (int32_t)f;
+    }
+    int rc = 0;
+    auto A = [&](int r) { if (!rc) rc = r; };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(SDFHIP_E_HIP, "hipStreamCreate failed");
+    A(dalloc(&h->d_verts, 3 * (size_t)nv));
+    A(dalloc(&h->d_faces, 3 * (size_t)nf));
+    A(dalloc(&h->d_kd_pts, 3 * (size_t)nv));
+    A(dalloc(&h->d_kd_vind, (size_t)nv));
+    A(dalloc(&h->d_adj_off, (size_t)nv + 1));
+    A(dalloc(&h->d_adj_faces, 3 * (size_t)nf));
+    A(dalloc(&h->d_geo, 4 * (size_t)nf));
+    A(dalloc(&h->d_normals, 3 * (size_t)nf));
+    A(dalloc(&h->d_areas, (size_t)nf));
+    A(dalloc(&h->d_rface, h->robust ? 3 * (size_t)nf : 1));
+    A(dalloc(&h->d_fbox, h->robust ? 6 * (size_t)nf : 1));
+    if (h->robust) {
+        A(dalloc(&h->d_rnodes, 2 * (size_t)(2 * (size_t)nf + 1)));
+        A(dalloc(&h->d_sorted_face, (size_t)nf));
+        A(dalloc(&h->d_codes, (size_t)nf));
+        A(dalloc(&h->d_maxdepth, 1));
+        A(dalloc(&h->topo.lo, (size_t)nf));
+        A(dalloc(&h->topo.hi, (size_t)nf));
+        A(dalloc(&h->topo.split, (size_t)nf));
+        A(dalloc(&h->topo.parentI, (size_t)nf));
+        A(dalloc(&h->topo.parentL, (size_t)nf));
+        A(dalloc(&h->topo.posI, (size_t)nf));
+        A(dalloc(&h->topo.posL, (size_t)nf));
+        A(dalloc(&h->topo.depthI, (size_t)nf));
+    }
+    if (!rc && nf) {
+        if (hipMemcpy(h->d_faces, h->h_faces, sizeof(uint32_t) * 3 * (size_t)nf, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_adj_faces, h->adj_faces.data(), sizeof(int32_t) * 3 * (size_t)nf, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(SDFHIP_E_HIP, "upload of faces failed");
+    }
+    if (!rc && hipMemcpy(h->d_adj_off, h->adj_off.data(), sizeof(uint32_t) * ((size_t)nv + 1), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(SDFHIP_E_HIP, "upload of adjacency failed");
+    if (!rc) rc = do_update(h, true);  // sdf.cpp:28 update(false): same work, kd built once
+    if (rc) {
+        std::string keep = g_err;
+        sdfhip_destroy(h);
+        g_err = keep;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+void sdfhip_destroy(sdfhip_t* h) {
+    if (!h) return;
+    DevGuard g(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_nodes, h->d_kd_pts, h->d_kd_vind, h->d_adj_off,
+                    h->d_adj_faces, h->d_geo, h->d_rface, h->d_fbox, h->d_normals, h->d_areas,
+                    h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
+                    h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
+                    h->topo.depthI, h->d_qkeys, h->d_qperm, h->d_qbounds, h->d_gstack};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    h->sorter.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int sdfhip_update(sdfhip_t* h) {
+    if (!h) return fail(SDFHIP_E_INVALID, "null handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DevGuard g(h->device);
+    if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
+    return do_update(h, true);
+}
+
+int sdfhip_update_from_device(sdfhip_t* h, const float* d_verts, void* stream) {
+    if (!h || !d_verts) return fail(SDFHIP_E_INVALID, "null handle/verts");
+    if (!h->own)
+        return fail(SDFHIP_E_STATE, "update_from_device needs an owning handle (copy=1): the host copy is refreshed");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DevGuard g(h->device);
+    if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
+    HIPC(hipMemcpyAsync(h->owned_verts.data(), d_verts, sizeof(float) * 3 * (size_t)h->nv,
+                        hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPC(hipStreamSynchronize((hipStream_t)stream));
+    return do_update(h, true);
+}
+
+int sdfhip_set_raycast_axes(sdfhip_t* h, const float R[9], int pin) {
+    if (!h) return fail(SDFHIP_E_INVALID, "null handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!pin) {
+        h->R_pinned = false;
+        return 0;
+    }
+    if (!R) return fail(SDFHIP_E_INVALID, "null R");
+    std::memcpy(h->R, R, 9 * sizeof(float));
+    h->R_pinned = true;
+    if (!h->robust) return 0;
+    DevGuard g(h->device);
+    if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
+    if (int rc = update_device_side(h)) return rc;
+    HIPC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int sdfhip_get_raycast_axes(const sdfhip_t* h, float R[9]) {
+    if (!h || !R) return fail(SDFHIP_E_INVALID, "null handle/R");
+    std::memcpy(R, h->R, 9 * sizeof(float));
+    return 0;
+}
+
+int sdfhip_sdf(sdfhip_t* h, const float* p, int64_t n, int trunc, float* out) {
+    return run_query_host(h, Q_SDF, p, n, trunc, out);
+}
+int sdfhip_sdf_device(sdfhip_t* h, const float* p, int64_t n, int trunc, float* out, void* s) {
+    return run_query_dev(h, Q_SDF, p, n, trunc, out, s);
+}
+int sdfhip_contains(sdfhip_t* h, const float* p, int64_t n, uint8_t* out) {
+    return run_query_host(h, Q_CONTAINS, p, n, 0, out);
+}
+int sdfhip_contains_device(sdfhip_t* h, const float* p, int64_t n, uint8_t* out, void* s) {
+    return run_query_dev(h, Q_CONTAINS, p, n, 0, out, s);
+}
+int sdfhip_nn(sdfhip_t* h, const float* p, int64_t n, int32_t* out) {
+    return run_query_host(h, Q_NN, p, n, 0, out);
+}
+int sdfhip_nn_device(sdfhip_t* h, const float* p, int64_t n, int32_t* out, void* s) {
+    return run_query_dev(h, Q_NN, p, n, 0, out, s);
+}
+int sdfhip_raycast_detail(sdfhip_t* h, const float* p, int64_t n, int32_t* out3) {
+    if (h && !h->robust) return fail(SDFHIP_E_STATE, "raycast detail needs a robust handle");
+    return run_query_host(h, Q_DETAIL, p, n, 0, out3);
+}
+
+int sdfhip_robust(const sdfhip_t* h) { return h ? h->robust : 0; }
+int sdfhip_own_data(const sdfhip_t* h) { return h ? h->own : 0; }
+int sdfhip_device(const sdfhip_t* h) { return h ? h->device : -1; }
+uint32_t sdfhip_num_verts(const sdfhip_t* h) { return h ? h->nv : 0; }
+uint32_t sdfhip_num_faces(const sdfhip_t* h) { return h ? h->nf : 0; }
+const float* sdfhip_verts(const sdfhip_t* h) { return h ? h->h_verts : nullptr; }
+const uint32_t* sdfhip_faces(const sdfhip_t* h) { return h ? h->h_faces : nullptr; }
+float* sdfhip_verts_mutable(sdfhip_t* h) {
+    if (!h) return nullptr;
+    if (!h->own) {
+        fail(SDFHIP_E_STATE, "'verts' is non mutable, construct with copy=True");
+        return nullptr;
+    }
+    return h->owned_verts.data();
+}
+uint32_t* sdfhip_faces_mutable(sdfhip_t* h) {
+    if (!h) return nullptr;
+    if (!h->own) {
+        fail(SDFHIP_E_STATE, "'faces' is non mutable, construct with copy=True");
+        return nullptr;
+    }
+    return h->owned_faces.data();
+}
+int sdfhip_surface_area(sdfhip_t* h, float* out) {
+    if (!h || !out) return fail(SDFHIP_E_INVALID, "null handle/out");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (int rc = fetch_face_host(h)) return rc;
+    float s = 0.f;
+    for (float a : h->h_areas) s += a;
+    *out = s;
+    return 0;
+}
+int sdfhip_face_areas(sdfhip_t* h, float* out) {
+    if (!h || !out) return fail(SDFHIP_E_INVALID, "null handle/out");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (int rc = fetch_face_host(h)) return rc;
+    std::memcpy(out, h->h_areas.data(), sizeof(float) * h->h_areas.size());
+    return 0;
+}
+int sdfhip_face_normals(sdfhip_t* h, float* out) {
+    if (!h || !out) return fail(SDFHIP_E_INVALID, "null handle/out");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (int rc = fetch_face_host(h)) return rc;
+    std::memcpy(out, h->h_normals.data(), sizeof(float) * h->h_normals.size());
+    return 0;
+}
+int sdfhip_aabb(const sdfhip_t* h, float out[6]) {
+    if (!h || !out) return fail(SDFHIP_E_INVALID, "null handle/out");
+    std::memcpy(out, h->aabb, 6 * sizeof(float));
+    return 0;
+}
+int sdfhip_adj_faces(const sdfhip_t* h, uint32_t v, const int32_t** ids) {
+    if (!h || !ids) return fail(SDFHIP_E_INVALID, "null handle/ids");
+    if (v >= h->nv) return fail(SDFHIP_E_INVALID, "vertex %u out of range", v);
+    *ids = h->adj_faces.data() + h->adj_off[v];
+    return (int)(h->adj_off[v + 1] - h->adj_off[v]);
+}
+int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* o) {
+    if (!h || !o) return fail(SDFHIP_E_INVALID, "null handle/out");
+    o->kd_nodes = (int32_t)h->kd.nodes.size();
+    o->kd_depth = h->kd.depth;
+    o->bvh_nodes = h->robust ? (int32_t)h->n_rnodes : 0;
+    o->bvh_depth = (int32_t)h->bvh_depth;
+    o->last_update_ms = h->last_update_ms;
+    o->last_kd_build_ms = h->last_kd_ms;
+    return 0;
+}
+int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
+    if (!h || !key) return fail(SDFHIP_E_INVALID, "null handle/key");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!strcmp(key, "sort_queries"))
+        h->opt_sort = v;
+    else if (!strcmp(key, "sort_min"))
+        h->opt_sort_min = v;
+    else if (!strcmp(key, "chunk")) {
+        if (v < 1024 || v > (1ll << 27)) return fail(SDFHIP_E_INVALID, "chunk must be in [1024, 2^27]");
+        h->opt_chunk = v;
+    } else
+        return fail(SDFHIP_E_INVALID, "unknown option '%s'", key);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,397 @@
+"""`pysdf`-compatible Python surface over the C ABI (include/sdfhip.h).
+
+Mirrors the reference's pybind module (pybind.cpp:14-83, 195): class `SDF` with the same
+constructor, `__call__`/`calc`, `contains`, `nn`, `update`, `sample_surface`, properties and
+`__repr__`, and the module attribute `num_threads`.  numpy inputs are converted like
+pybind11/eigen.h does (float64 -> float32, int64 -> uint32, a length-3 vector is a 1x3
+point; README.md:24-25, 103-106) and numpy results are returned.  torch tensors that live on
+the handle's GPU are passed to the `_device` entry points without a host round trip and a
+tensor on the same device is returned.
+
+There is no CPU fallback: importing works anywhere, constructing an SDF needs the built
+`libsdfhip.so` and a HIP device and raises otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libsdfhip.so")
+
+# pybind.cpp:12 / 195
+num_threads = min(os.cpu_count() or 1, 32)
+
+_fp = C.POINTER(C.c_float)
+_up = C.POINTER(C.c_uint32)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_uint8)
+
+
+class SdfHipError(RuntimeError):
+    pass
+
+
+class _Stats(C.Structure):
+    _fields_ = [("kd_nodes", C.c_int32), ("kd_depth", C.c_int32), ("bvh_nodes", C.c_int32),
+                ("bvh_depth", C.c_int32), ("last_update_ms", C.c_float),
+                ("last_kd_build_ms", C.c_float)]
+
+
+_lib = None
+
+# every symbol include/sdfhip.h declares (tests check that the library exports them all)
+ABI_SYMBOLS = [
+    "sdfhip_create", "sdfhip_destroy", "sdfhip_update", "sdfhip_update_from_device",
+    "sdfhip_set_raycast_axes", "sdfhip_get_raycast_axes", "sdfhip_sdf", "sdfhip_sdf_device",
+    "sdfhip_contains", "sdfhip_contains_device", "sdfhip_nn", "sdfhip_nn_device",
+    "sdfhip_raycast_detail", "sdfhip_robust", "sdfhip_own_data", "sdfhip_device",
+    "sdfhip_num_verts", "sdfhip_num_faces", "sdfhip_verts", "sdfhip_faces",
+    "sdfhip_verts_mutable", "sdfhip_faces_mutable", "sdfhip_surface_area", "sdfhip_face_areas",
+    "sdfhip_face_normals", "sdfhip_aabb", "sdfhip_adj_faces", "sdfhip_get_stats",
+    "sdfhip_set_option", "sdfhip_last_error", "sdfhip_version",
+]
+
+
+def load_library():
+    """Load libsdfhip.so (built in-tree by `__graft_entry__.build()` / sdf_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIBPATH):
+        raise SdfHipError(
+            f"{_LIBPATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc, gfx950).  There is no CPU fallback.")
+    L = C.CDLL(_LIBPATH)
+    vp = C.c_void_p
+    L.sdfhip_create.restype = C.c_int
+    L.sdfhip_create.argtypes = [_fp, C.c_uint32, _up, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                C.POINTER(vp)]
+    L.sdfhip_destroy.restype = None
+    L.sdfhip_destroy.argtypes = [vp]
+    L.sdfhip_update.argtypes = [vp]
+    L.sdfhip_update_from_device.argtypes = [vp, vp, vp]
+    L.sdfhip_set_raycast_axes.argtypes = [vp, _fp, C.c_int]
+    L.sdfhip_get_raycast_axes.argtypes = [vp, _fp]
+    L.sdfhip_sdf.argtypes = [vp, _fp, C.c_int64, C.c_int, _fp]
+    L.sdfhip_sdf_device.argtypes = [vp, vp, C.c_int64, C.c_int, vp, vp]
+    L.sdfhip_contains.argtypes = [vp, _fp, C.c_int64, _bp]
+    L.sdfhip_contains_device.argtypes = [vp, vp, C.c_int64, vp, vp]
+    L.sdfhip_nn.argtypes = [vp, _fp, C.c_int64, _ip]
+    L.sdfhip_nn_device.argtypes = [vp, vp, C.c_int64, vp, vp]
+    L.sdfhip_raycast_detail.argtypes = [vp, _fp, C.c_int64, _ip]
+    for name in ("sdfhip_robust", "sdfhip_own_data", "sdfhip_device"):
+        getattr(L, name).argtypes = [vp]
+    L.sdfhip_num_verts.restype = C.c_uint32
+    L.sdfhip_num_verts.argtypes = [vp]
+    L.sdfhip_num_faces.restype = C.c_uint32
+    L.sdfhip_num_faces.argtypes = [vp]
+    L.sdfhip_verts.restype = _fp
+    L.sdfhip_verts.argtypes = [vp]
+    L.sdfhip_faces.restype = _up
+    L.sdfhip_faces.argtypes = [vp]
+    L.sdfhip_verts_mutable.restype = _fp
+    L.sdfhip_verts_mutable.argtypes = [vp]
+    L.sdfhip_faces_mutable.restype = _up
+    L.sdfhip_faces_mutable.argtypes = [vp]
+    L.sdfhip_surface_area.argtypes = [vp, _fp]
+    L.sdfhip_face_areas.argtypes = [vp, _fp]
+    L.sdfhip_face_normals.argtypes = [vp, _fp]
+    L.sdfhip_aabb.argtypes = [vp, _fp]
+    L.sdfhip_adj_faces.argtypes = [vp, C.c_uint32, C.POINTER(_ip)]
+    L.sdfhip_get_stats.argtypes = [vp, C.POINTER(_Stats)]
+    L.sdfhip_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.sdfhip_last_error.restype = C.c_char_p
+    L.sdfhip_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SdfHipError(f"sdfhip error {rc}: {load_library().sdfhip_last_error().decode()}")
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def _as_points(points):
+    p = np.asarray(points)
+    if p.ndim == 1 and p.shape[0] == 3:
+        p = p.reshape(1, 3)
+    if p.ndim != 2 or p.shape[1] != 3:
+        raise TypeError("points must have shape (N, 3)")
+    return np.ascontiguousarray(p, dtype=np.float32)
+
+
+class SDF:
+    """Signed-distance / containment / nearest-vertex queries on a triangle mesh, on one
+    MI355X.  Same call surface as `pysdf.SDF` (pybind.cpp:18-83)."""
+
+    def __init__(self, verts, faces, robust=True, copy=True, device=None):
+        L = load_library()
+        v = np.asarray(verts)
+        f = np.asarray(faces)
+        if v.ndim != 2 or v.shape[1] != 3 or f.ndim != 2 or f.shape[1] != 3:
+            raise TypeError("verts must be (V, 3) and faces (F, 3)")
+        if f.size and (f.min() < 0):
+            raise TypeError("faces must be non-negative")
+        v32 = np.ascontiguousarray(v, dtype=np.float32)
+        f32 = np.ascontiguousarray(f, dtype=np.uint32)
+        if not copy:
+            # Eigen::Ref semantics (sdf.cpp:339): the handle keeps reading this memory.  A dtype
+            # or layout conversion would silently detach it from the caller's array.
+            if v32 is not v and not np.shares_memory(v32, v):
+                raise TypeError("copy=False needs C-contiguous float32 verts")
+            if f32 is not f and not np.shares_memory(f32, f):
+                raise TypeError("copy=False needs C-contiguous uint32 faces")
+        self._keep = (v32, f32)  # keep borrowed memory alive
+        h = C.c_void_p()
+        dev = -1 if device is None else int(device)
+        _check(L.sdfhip_create(v32.ctypes.data_as(_fp), v32.shape[0], f32.ctypes.data_as(_up),
+                               f32.shape[0], int(bool(robust)), int(bool(copy)), dev, C.byref(h)))
+        self._h = h
+        self._L = L
+        if copy:
+            self._keep = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.sdfhip_destroy(h)
+            self._h = None
+
+    # ---- queries -----------------------------------------------------------------------
+    def _query(self, kind, points, trunc_aabb=False):
+        L = self._L
+        if _is_torch(points):
+            import torch
+            t = points
+            if t.dim() == 1 and t.shape[0] == 3:
+                t = t.reshape(1, 3)
+            if t.dim() != 2 or t.shape[1] != 3:
+                raise TypeError("points must have shape (N, 3)")
+            if t.is_cuda:
+                if t.device.index != self.device:
+                    raise SdfHipError("points tensor is on another GPU than the SDF handle")
+                t = t.contiguous().float()
+                n = t.shape[0]
+                dt = {"sdf": torch.float32, "contains": torch.uint8, "nn": torch.int32}[kind]
+                out = torch.empty(n, dtype=dt, device=t.device)
+                s = torch.cuda.current_stream(t.device).cuda_stream
+                if kind == "sdf":
+                    _check(L.sdfhip_sdf_device(self._h, t.data_ptr(), n, int(trunc_aabb),
+                                               out.data_ptr(), s))
+                elif kind == "contains":
+                    _check(L.sdfhip_contains_device(self._h, t.data_ptr(), n, out.data_ptr(), s))
+                    out = out.bool()
+                else:
+                    _check(L.sdfhip_nn_device(self._h, t.data_ptr(), n, out.data_ptr(), s))
+                return out
+            points = t.detach().cpu().numpy()
+        p = _as_points(points)
+        n = p.shape[0]
+        if kind == "sdf":
+            out = np.empty(n, dtype=np.float32)
+            _check(L.sdfhip_sdf(self._h, p.ctypes.data_as(_fp), n, int(trunc_aabb),
+                                out.ctypes.data_as(_fp)))
+            return out
+        if kind == "contains":
+            out = np.empty(n, dtype=np.uint8)
+            _check(L.sdfhip_contains(self._h, p.ctypes.data_as(_fp), n, out.ctypes.data_as(_bp)))
+            return out.view(np.bool_)
+        out = np.empty(n, dtype=np.int32)
+        _check(L.sdfhip_nn(self._h, p.ctypes.data_as(_fp), n, out.ctypes.data_as(_ip)))
+        return out
+
+    def __call__(self, points, trunc_aabb=False, n_threads=num_threads):
+        """Compute SDF on points (positive iff inside)."""
+        return self._query("sdf", points, trunc_aabb)
+
+    def calc(self, points, trunc_aabb=False, n_threads=num_threads):
+        """Compute SDF on points (positive iff inside), alias of __call__."""
+        return self._query("sdf", points, trunc_aabb)
+
+    def contains(self, points, n_threads=num_threads):
+        """Test if points are in mesh."""
+        return self._query("contains", points)
+
+    def nn(self, points, n_threads=num_threads):
+        """Find nearest neighbor indices."""
+        return self._query("nn", points)
+
+    def update(self):
+        """Update the SDF to reflect any changes in verts."""
+        _check(self._L.sdfhip_update(self._h))
+
+    def update_from_device(self, verts_tensor):
+        """update() with the new vertex positions taken from a GPU tensor (V, 3) float32."""
+        import torch
+        t = verts_tensor.contiguous().float()
+        if tuple(t.shape) != (self._nv, 3):
+            raise TypeError("verts tensor must have the shape of the mesh vertices")
+        s = torch.cuda.current_stream(t.device).cuda_stream
+        _check(self._L.sdfhip_update_from_device(self._h, t.data_ptr(), s))
+
+    def raycast_detail(self, points):
+        p = _as_points(points)
+        out = np.empty((p.shape[0], 3), dtype=np.int32)
+        _check(self._L.sdfhip_raycast_detail(self._h, p.ctypes.data_as(_fp), p.shape[0],
+                                             out.ctypes.data_as(_ip)))
+        return out
+
+    def sample_surface(self, num_points):
+        """Sample num_points uniformly random points on the mesh surface (sdf.cpp:176-234):
+        pick a face with probability proportional to its area, then a uniform point in it
+        (parallelogram sample reflected over bc).  Host-side numpy: outside the GPU hot path
+        (SURVEY.md §8f), random by construction so only distribution-level parity applies."""
+        areas = self.face_areas
+        if areas.shape[0] == 0:
+            import sys
+            print("ERROR: No faces, can't sample surface.", file=sys.stderr)
+            return np.zeros((0, 3), dtype=np.float32)
+        rng = np.random.default_rng()
+        cum = np.cumsum(areas, dtype=np.float32)
+        r = rng.uniform(0, 1, num_points).astype(np.float32) * np.float32(self.surface_area)
+        fi = np.clip(np.searchsorted(cum, r, side="left"), 0, areas.shape[0] - 1)
+        F = self.faces[fi].astype(np.int64)
+        V = self.verts
+        a, b, c = V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]
+        ab, ac, bc = b - a, c - a, c - b
+        perp = np.cross(bc, self.face_normals[fi])
+        perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+        a_dir = (ab * perp).sum(1) < 0
+        u = rng.uniform(0, 1, (num_points, 1)).astype(np.float32)
+        w = rng.uniform(0, 1, (num_points, 1)).astype(np.float32)
+        res = a + u * ab + w * ac
+        bp = ((res - b) * perp).sum(1)
+        flip = (bp >= 0) != a_dir
+        res[flip] -= (bp[flip, None] * perp[flip]) * 2.0
+        return res.astype(np.float32)
+
+    # ---- rotation injection (no counterpart: the reference's R is private + random) -----
+    def set_raycast_axes(self, R, pin=True):
+        R = np.ascontiguousarray(R, dtype=np.float32).reshape(9)
+        _check(self._L.sdfhip_set_raycast_axes(self._h, R.ctypes.data_as(_fp), int(pin)))
+
+    @property
+    def raycast_axes(self):
+        R = np.empty(9, dtype=np.float32)
+        _check(self._L.sdfhip_get_raycast_axes(self._h, R.ctypes.data_as(_fp)))
+        return R.reshape(3, 3)
+
+    def set_option(self, key, value):
+        _check(self._L.sdfhip_set_option(self._h, key.encode(), int(value)))
+
+    @property
+    def stats(self):
+        s = _Stats()
+        _check(self._L.sdfhip_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _Stats._fields_}
+
+    # ---- data accessors (pybind.cpp:39-77) ------------------------------------------------
+    @property
+    def _nv(self):
+        return int(self._L.sdfhip_num_verts(self._h))
+
+    @property
+    def _nf(self):
+        return int(self._L.sdfhip_num_faces(self._h))
+
+    @property
+    def device(self):
+        return int(self._L.sdfhip_device(self._h))
+
+    @property
+    def surface_area(self):
+        out = C.c_float()
+        _check(self._L.sdfhip_surface_area(self._h, C.byref(out)))
+        return float(out.value)
+
+    @property
+    def face_areas(self):
+        out = np.empty(self._nf, dtype=np.float32)
+        _check(self._L.sdfhip_face_areas(self._h, out.ctypes.data_as(_fp)))
+        return out
+
+    @property
+    def face_normals(self):
+        out = np.empty((self._nf, 3), dtype=np.float32)
+        _check(self._L.sdfhip_face_normals(self._h, out.ctypes.data_as(_fp)))
+        return out
+
+    @property
+    def aabb(self):
+        out = np.empty(6, dtype=np.float32)
+        _check(self._L.sdfhip_aabb(self._h, out.ctypes.data_as(_fp)))
+        return out
+
+    def _view(self, ptr, shape, dtype, writable):
+        if shape[0] == 0:
+            return np.zeros(shape, dtype=dtype)
+        n = int(np.prod(shape))
+        arr = np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).reshape(shape)
+        arr.flags.writeable = writable
+        return arr
+
+    @property
+    def faces(self):
+        return self._view(self._L.sdfhip_faces(self._h), (self._nf, 3), np.uint32, False)
+
+    @property
+    def verts(self):
+        return self._view(self._L.sdfhip_verts(self._h), (self._nv, 3), np.float32, False)
+
+    vertices = verts
+
+    def _mutable(self, which):
+        import sys
+        if not self.own_data:
+            # sdf.cpp:360-375: prints and returns the (empty) owned matrix
+            print(f"ERROR: '{which}' is non mutable, construct with copy=True", file=sys.stderr)
+            return np.zeros((0, 3), dtype=np.float32 if which == "verts" else np.uint32)
+        if which == "verts":
+            return self._view(self._L.sdfhip_verts_mutable(self._h), (self._nv, 3), np.float32, True)
+        return self._view(self._L.sdfhip_faces_mutable(self._h), (self._nf, 3), np.uint32, True)
+
+    @property
+    def verts_mutable(self):
+        return self._mutable("verts")
+
+    @verts_mutable.setter
+    def verts_mutable(self, val):
+        dst = self._mutable("verts")
+        dst[...] = np.asarray(val, dtype=np.float32).reshape(dst.shape)  # pybind.cpp:60-62
+
+    vertices_mutable = verts_mutable
+
+    @property
+    def faces_mutable(self):
+        return self._mutable("faces")
+
+    @faces_mutable.setter
+    def faces_mutable(self, val):
+        dst = self._mutable("faces")
+        dst[...] = np.asarray(val, dtype=np.uint32).reshape(dst.shape)
+
+    @property
+    def robust(self):
+        return bool(self._L.sdfhip_robust(self._h))
+
+    @property
+    def own_data(self):
+        return bool(self._L.sdfhip_own_data(self._h))
+
+    def adj_faces(self, pointid):
+        ids = _ip()
+        n = self._L.sdfhip_adj_faces(self._h, int(pointid), C.byref(ids))
+        if n < 0:
+            _check(n)
+        return [int(ids[i]) for i in range(n)]
+
+    def __repr__(self):
+        return (f"<sdf.SDF(verts.shape=({self._nv}, 3), faces.shape=({self._nf}, 3), "
+                f"robust={'True' if self.robust else 'False'})>")

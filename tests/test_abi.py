@@ -1,0 +1,74 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports
+every symbol include/sdfhip.h declares; host-side argument checking works without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sdf_amd
+from sdf_amd import pysdf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "sdfhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdfhip_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = pysdf.load_library()
+    decl = _declared()
+    assert len(decl) >= 25
+    for name in decl:
+        assert hasattr(L, name), f"{name} declared in sdfhip.h but not exported"
+    assert sorted(pysdf.ABI_SYMBOLS) == decl
+
+
+def test_version_and_error_string():
+    L = pysdf.load_library()
+    assert b"gfx950" in L.sdfhip_version()
+    assert isinstance(L.sdfhip_last_error(), bytes)
+
+
+def test_create_rejects_bad_arguments_before_touching_the_gpu():
+    L = pysdf.load_library()
+    v = np.zeros((3, 3), np.float32)
+    f = np.array([[0, 1, 7]], np.uint32)  # index out of range
+    h = C.c_void_p()
+    rc = L.sdfhip_create(v.ctypes.data_as(pysdf._fp), 3, f.ctypes.data_as(pysdf._up), 1, 1, 1, -1,
+                         C.byref(h))
+    assert rc == -1 and b"out of range" in L.sdfhip_last_error() and not h.value
+    assert L.sdfhip_create(None, 3, None, 1, 1, 1, -1, C.byref(h)) == -1
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    v, f = sdf_amd.meshes.cube()
+    with pytest.raises(sdf_amd.SdfHipError) as e:
+        sdf_amd.SDF(v, f)
+    assert "no HIP device" in str(e.value) or "error -3" in str(e.value) or "error -2" in str(e.value)
+
+
+def test_python_surface_matches_pysdf():
+    """names and defaults of pybind.cpp:18-83, 195"""
+    import inspect
+    S = sdf_amd.SDF
+    sig = inspect.signature(S.__init__)
+    assert list(sig.parameters)[1:5] == ["verts", "faces", "robust", "copy"]
+    assert sig.parameters["robust"].default is True and sig.parameters["copy"].default is True
+    for name in ("__call__", "calc"):
+        p = inspect.signature(getattr(S, name)).parameters
+        assert list(p)[1:] == ["points", "trunc_aabb", "n_threads"] and p["trunc_aabb"].default is False
+    for name in ("contains", "nn"):
+        assert list(inspect.signature(getattr(S, name)).parameters)[1:] == ["points", "n_threads"]
+    for name in ("update", "sample_surface", "surface_area", "face_areas", "face_normals", "aabb",
+                 "faces", "verts", "vertices", "faces_mutable", "verts_mutable", "vertices_mutable",
+                 "robust", "own_data", "__repr__"):
+        assert hasattr(S, name)
+    assert sdf_amd.num_threads == min(os.cpu_count(), 32)
