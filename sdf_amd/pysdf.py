@@ -64,6 +64,13 @@ def load_library():
         raise SdfHipError(
             f"{_LIBPATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc, gfx950).  There is no CPU fallback.")
+    # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME as
+    # /opt/rocm's).  Loading torch first makes this library bind to that copy; the other
+    # order would put two runtimes in the process and the second finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_LIBPATH)
     vp = C.c_void_p
     L.sdfhip_create.restype = C.c_int
