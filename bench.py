@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py — robust SDF evals/s on the ~360k-face configuration of BASELINE.json.
+
+Workload (BASELINE.json configs[3], the one the metric is quoted on): synthetic torus
+424 x 424 (179,776 verts / 359,552 faces), robust `SDF.__call__` on uniform random points in
+[-1,1]^3 generated ON DEVICE (seed 7 + rank), 1e9 / 8 = 125,000,000 points per GPU per step
+(weak scaling: every rank processes its own shard; no data-path collective).  The mesh and the
+ray-cast rotation are created on rank 0 and replicated with an RCCL broadcast; every rank then
+builds the same structures.  One "step" = one pass of the hot path over the rank's batch, with
+inputs resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import sdf_amd  # noqa: E402
+from sdf_amd import meshes  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_EVAL = 16    # 12 B point read + 4 B result write
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=125_000_000, help="points per GPU per step")
+    ap.add_argument("--mesh-res", type=int, default=424, help="torus tessellation (424 -> 359,552 faces)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grid", action="store_true")
+    ap.add_argument("--no-sort", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(v, f, R, seed):
+    """The oracle (a port of the reference's CPU path with the same self-scheduling threads,
+    util.cpp:7-29) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import pyoracle as po
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit():
+        cores = min(cores, int(env))
+    threads = max(1, min(cores, 32))  # pybind.cpp:12 caps the default at 32
+    o = po.OracleSDF(v, f, True, R)
+    rng = np.random.default_rng(seed)
+    n = 500_000
+    pts = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    t0 = time.perf_counter()
+    o(pts, n_threads=threads)
+    dt = time.perf_counter() - t0
+    rate = n / dt
+    n2 = int(min(max(rate * 12.0, n), 16_000_000))
+    if n2 > n:
+        pts = rng.uniform(-1, 1, (n2, 3)).astype(np.float32)
+        t0 = time.perf_counter()
+        o(pts, n_threads=threads)
+        dt = time.perf_counter() - t0
+        n = n2
+    return {"value": n / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": f"{n} of the step's uniform random points, same mesh and rotation, "
+                      f"{dt:.1f} s wall, oracle/liboracle.so with {threads} threads"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- mesh: built on rank 0, replicated by RCCL broadcast --------------------------------
+    res = a.mesh_res
+    nv, nf = res * res, 2 * res * res
+    if rank == 0:
+        v, f = meshes.torus(res, res)
+        R = meshes.random_rotation(1234)
+        tv = torch.from_numpy(v).to(dev)
+        tf = torch.from_numpy(f.astype(np.int32)).to(dev)
+        tR = torch.from_numpy(R).to(dev)
+    else:
+        tv = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+        tf = torch.empty((nf, 3), dtype=torch.int32, device=dev)
+        tR = torch.empty((3, 3), dtype=torch.float32, device=dev)
+    if dist is not None:
+        dist.broadcast(tv, 0)
+        dist.broadcast(tf, 0)
+        dist.broadcast(tR, 0)
+    v = tv.cpu().numpy()
+    f = tf.cpu().numpy().astype(np.uint32)
+    R = tR.cpu().numpy()
+    s = sdf_amd.SDF(v, f, robust=True, copy=True, device=local)
+    s.set_raycast_axes(R)
+    if a.no_sort:
+        s.set_option("sort_queries", 0)
+
+    # ---- inputs resident in HBM ----------------------------------------------------------------
+    n = a.points
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    pts = torch.rand((n, 3), device=dev, generator=g, dtype=torch.float32).mul_(2).sub_(1)
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    L = s._L
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        rc = L.sdfhip_sdf_device(s._h, pts.data_ptr(), n, 0, out.data_ptr(), stream)
+        if rc:
+            raise RuntimeError(L.sdfhip_last_error().decode())
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    s.set_option("profile", 2)  # hipEvents around every query-kernel launch, counters reset
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    st = s.stats
+    s.set_option("profile", 0)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    total = n * world * a.steps
+    value = total / dt
+    # dominant kernel: k_query<SDF, robust>; algorithmic bytes per launch = 16 B x points/launch
+    kl = max(1, st["query_kernel_launches"])
+    k_ms = st["query_kernel_ms"] / kl
+    pts_per_launch = st["query_kernel_points"] / kl
+    achieved = BYTES_PER_EVAL * pts_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_query<Q_SDF,robust>", "kernel_ms_avg": k_ms,
+                "points_per_launch": pts_per_launch, "launches": kl,
+                "kernel_share_of_step": st["query_kernel_ms"] / (dt * 1e3)}
+    extra = {}
+    if not a.no_grid:
+        # the metric's second figure: ms for a 256^3 grid (16,777,216 points) on the same mesh
+        t = torch.linspace(-1, 1, 256, device=dev)
+        gp = torch.stack(torch.meshgrid(t, t, t, indexing="ij"), -1).reshape(-1, 3).contiguous()
+        go = torch.empty(gp.shape[0], dtype=torch.float32, device=dev)
+        ms = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            L.sdfhip_sdf_device(s._h, gp.data_ptr(), gp.shape[0], 0, go.data_ptr(), stream)
+            torch.cuda.synchronize(dev)
+            ms.append((time.perf_counter() - t1) * 1e3)
+        extra["grid256_ms"] = min(ms)
+        extra["grid256_inside"] = int((go > 0).sum().item())
+    extra["update_ms"] = s.stats["last_update_ms"]
+    extra["kd_build_ms"] = s.stats["last_kd_build_ms"]
+    line = {
+        "metric": "robust SDF evals/s, ~360k-face mesh",
+        "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[3]: torus {res}x{res} ({nv} verts / {nf} faces), robust "
+                               f"SDF on {n} uniform random points in [-1,1]^3 per GPU per step "
+                               f"(1e9/8 per GPU), device-resident, seed 7+rank",
+                   "points_per_gpu": n, "faces": nf, "verts": nv, "sort_queries": not a.no_sort},
+        "roofline": roofline,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(v, f, R, 7)
+    line["extra"] = extra
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

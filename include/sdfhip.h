@@ -128,11 +128,17 @@ typedef struct {
     int32_t bvh_depth;
     float last_update_ms;  /* wall time of the last create/update */
     float last_kd_build_ms;
+    /* live hipEvent timing of the query kernels, accumulated while option "profile" != 0:
+     * total kernel time, number of launches and points they processed */
+    double query_kernel_ms;
+    int64_t query_kernel_launches;
+    int64_t query_kernel_points;
 } sdfhip_stats_t;
 int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* out);
 
 /* Tuning knobs (no counterpart). key: "sort_queries" (0/1, default 1: Morton-sort query
- * chunks of >= sort_min points), "sort_min", "chunk" (points per internal chunk). */
+ * chunks of >= sort_min points), "sort_min", "chunk" (points per internal chunk), "profile" (1: time every query kernel launch
+ * with hipEvents on its stream, read back through sdfhip_get_stats; 2: same and reset). */
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t value);
 
 const char* sdfhip_last_error(void);

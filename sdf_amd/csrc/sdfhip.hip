@@ -882,6 +882,11 @@ struct sdfhip_ctx {
     std::mutex mu;
     std::mt19937 rng;
     float last_update_ms = 0.f, last_kd_ms = 0.f;
+    // optional live profiling of the query kernels (hipEvents on the launch stream)
+    int64_t opt_profile = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending, prof_free;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0, prof_points = 0;
 };
 
 namespace {
@@ -1048,6 +1053,17 @@ int launch_query(sdfhip_ctx* h, const MeshDev& M, const float* d_pts, const uint
                  int trunc, void* d_out, hipStream_t s) {
     const bool needs_kd = !(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST));
     const uint32_t depth = (uint32_t)(h->kd.depth > 0 ? h->kd.depth : 1);
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (h->opt_profile && h->prof_pending.size() < 8192) {
+        if (!h->prof_free.empty()) {
+            ev = h->prof_free.back();
+            h->prof_free.pop_back();
+        } else {
+            HIPC(hipEventCreate(&ev.first));
+            HIPC(hipEventCreate(&ev.second));
+        }
+        HIPC(hipEventRecord(ev.first, s));
+    }
     const int64_t blocks_full = (n + QBLOCK - 1) / QBLOCK;
     if (needs_kd && depth > (uint32_t)LDS_DEPTH_MAX) {
         const int64_t blocks = blocks_full < 4096 ? blocks_full : 4096;
@@ -1063,6 +1079,11 @@ int launch_query(sdfhip_ctx* h, const MeshDev& M, const float* d_pts, const uint
         const int64_t blocks = blocks_full < 0x7FFFFFFF ? blocks_full : 0x7FFFFFFF;
         k_query<KIND, ROBUST, false><<<(uint32_t)blocks, QBLOCK, lds, s>>>(M, d_pts, perm, n, trunc,
                                                                            d_out, nullptr, depth);
+    }
+    if (ev.first) {
+        HIPC(hipEventRecord(ev.second, s));
+        h->prof_pending.push_back(ev);
+        h->prof_points += n;
     }
     HIPC(hipGetLastError());
     return 0;
@@ -1299,6 +1320,8 @@ void sdfhip_destroy(sdfhip_t* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->sorter.release();
+    for (auto& ev : h->prof_pending) (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
+    for (auto& ev : h->prof_free) (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1435,6 +1458,24 @@ int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* o) {
     o->bvh_depth = (int32_t)h->bvh_depth;
     o->last_update_ms = h->last_update_ms;
     o->last_kd_build_ms = h->last_kd_ms;
+    sdfhip_ctx* hm = const_cast<sdfhip_ctx*>(h);
+    {
+        std::lock_guard<std::mutex> lk(hm->mu);
+        DevGuard g(h->device);
+        for (auto& ev : hm->prof_pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(ev.second) == hipSuccess &&
+                hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                hm->prof_ms += ms;
+                hm->prof_launches++;
+            }
+            hm->prof_free.push_back(ev);
+        }
+        hm->prof_pending.clear();
+    }
+    o->query_kernel_ms = h->prof_ms;
+    o->query_kernel_launches = h->prof_launches;
+    o->query_kernel_points = h->prof_points;
     return 0;
 }
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
@@ -1442,6 +1483,10 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
     std::lock_guard<std::mutex> lk(h->mu);
     if (!strcmp(key, "sort_queries"))
         h->opt_sort = v;
+    else if (!strcmp(key, "profile")) {
+        h->opt_profile = v;
+        if (v == 2) h->prof_ms = 0.0, h->prof_launches = 0, h->prof_points = 0;  // reset
+    }
     else if (!strcmp(key, "sort_min"))
         h->opt_sort_min = v;
     else if (!strcmp(key, "chunk")) {
