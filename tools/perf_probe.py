@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Times nn / contains / sdf separately (device-resident points) for kernel tuning."""
+import argparse, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sdf_amd
+from sdf_amd import meshes
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--res", type=int, default=424)
+ap.add_argument("--n", type=int, default=16_000_000)
+ap.add_argument("--grid", type=int, default=0)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--robust", type=int, default=1)
+a = ap.parse_args()
+v, f = meshes.torus(a.res, a.res)
+s = sdf_amd.SDF(v, f, robust=bool(a.robust))
+s.set_raycast_axes(meshes.random_rotation(1234))
+dev = torch.device("cuda", 0)
+if a.grid:
+    t = torch.linspace(-1, 1, a.grid, device=dev)
+    pts = torch.stack(torch.meshgrid(t, t, t, indexing="ij"), -1).reshape(-1, 3).contiguous()
+else:
+    g = torch.Generator(device=dev).manual_seed(7)
+    pts = torch.rand((a.n, 3), device=dev, generator=g).mul_(2).sub_(1)
+n = pts.shape[0]
+print("stats", s.stats)
+for name, fn in (("nn", s.nn), ("contains", s.contains), ("sdf", s.__call__)):
+    fn(pts); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(a.reps):
+        t0 = time.perf_counter(); fn(pts); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    print(f"{name:9s} {best*1e3:9.2f} ms  {n/best/1e6:9.1f} Mevals/s", flush=True)
