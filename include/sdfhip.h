@@ -133,6 +133,8 @@ typedef struct {
     double query_kernel_ms;
     int64_t query_kernel_launches;
     int64_t query_kernel_points;
+    /* queries of the last packet-kernel launch that were deferred to the strict kernel */
+    int64_t last_fallback_points;
 } sdfhip_stats_t;
 int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* out);
 

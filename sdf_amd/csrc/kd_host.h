@@ -31,9 +31,21 @@ constexpr uint32_t KD_FEAT_SHIFT = 29;
 constexpr uint32_t KD_REF_MASK = 0x1FFFFFFFu;  // strips leaf bit and feat bits
 constexpr uint32_t KD_MAX_POINTS = 1u << 25;
 
+// tight AABBs of the two children of an internal node (what nanoflann's divideTree returns
+// through its bbox argument, nanoflann.hpp:889-903): lo1 hi1 lo2 hi2.  Used only for exact
+// no-op skipping / the packet traversal; not part of nanoflann's own search.
+struct KdChildBoxesH {  // 64 B
+    float lo1[3], hi1[3], lo2[3], hi2[3];
+    uint32_t split;  // first tree-order position of child 2's vertices (child 1: [.., split))
+    uint32_t pad[3];
+};
+
+static_assert(sizeof(KdChildBoxesH) == 64, "device layout");
+
 struct KdHost {
     std::vector<int32_t> vind;
     std::vector<KdNodeH> nodes;
+    std::vector<KdChildBoxesH> boxes;  // parallel to nodes
     uint32_t root_ref = KD_LEAF_BIT;  // empty leaf
     int depth = 0;                    // max internal nodes on a root-to-leaf path
     float bbox[6] = {0, 0, 0, 0, 0, 0};  // min xyz, max xyz (= mesh AABB, sdf.cpp:36-37)
@@ -127,6 +139,7 @@ inline uint32_t KdHost::split(int32_t left, int32_t right, Box& box, int level) 
     // --- recurse; children return their tight boxes (nanoflann.hpp:889-903) ---
     const uint32_t self = (uint32_t)nodes.size();
     nodes.push_back({});
+    boxes.push_back({});
     Box lb = box, rb = box;
     lb.hi[feat] = cut;
     rb.lo[feat] = cut;
@@ -137,6 +150,11 @@ inline uint32_t KdHost::split(int32_t left, int32_t right, Box& box, int level) 
     nd.divhigh = rb.lo[feat];
     nd.ref1 = r1 | ((uint32_t)feat << KD_FEAT_SHIFT);
     nd.ref2 = r2;
+    KdChildBoxesH& cb = boxes[self];
+    cb.split = (uint32_t)(left + mid);
+    cb.pad[0] = cb.pad[1] = cb.pad[2] = 0;
+    for (int d = 0; d < 3; ++d)
+        cb.lo1[d] = lb.lo[d], cb.hi1[d] = lb.hi[d], cb.lo2[d] = rb.lo[d], cb.hi2[d] = rb.hi[d];
     for (int d = 0; d < 3; ++d) {
         box.lo[d] = lb.lo[d] < rb.lo[d] ? lb.lo[d] : rb.lo[d];
         box.hi[d] = lb.hi[d] > rb.hi[d] ? lb.hi[d] : rb.hi[d];
@@ -150,6 +168,8 @@ inline void KdHost::build(const float* pts, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) vind[i] = (int32_t)i;
     nodes.clear();
     nodes.reserve(n / 4 + 8);
+    boxes.clear();
+    boxes.reserve(n / 4 + 8);
     depth = 0;
     root_ref = KD_LEAF_BIT;
     for (int d = 0; d < 6; ++d) bbox[d] = 0;

@@ -74,6 +74,11 @@ struct MeshDev {
     const int32_t* kd_vind;
     uint32_t kd_root;
     float bb[6];  // mesh AABB == kd root bbox
+    // packet traversal extras: tight child boxes (12 floats / internal node), padded points,
+    // ambiguity factor c = 1 + W (see k_query_packet)
+    const float* kd_boxes;  // 16 dwords / internal node: lo1 hi1 lo2 hi2, split position, pad
+    const float4* kd_pts4;
+    float amb_c, amb_c2;
     // adjacency + face geometry
     const uint32_t* adj_off;
     const int32_t* adj_faces;
@@ -107,6 +112,18 @@ constexpr int LDS_DEPTH_MAX = 40; // deeper kd-trees use the global-memory stack
 // kd depth.  `stk` points at this lane's word of slot 0; consecutive words are `stride`
 // dwords apart.
 // =========================================================================================
+// Exact no-op skipping: a subtree whose tight vertex box is at least `best` away (box_lb below:
+// a rigorous lower bound of every computed vertex distance in it) cannot change (best, index)
+// — nanoflann only replaces on dist < best — and dists[] is restored after any subtree, so not
+// entering it leaves the search state exactly as nanoflann's own visit would.
+__device__ __forceinline__ float box_lb(float qx, float qy, float qz, float lx, float ly, float lz,
+                                        float hx, float hy, float hz) {
+    const float gx = fmaxf(fmaxf(lx - qx, qx - hx), 0.f);
+    const float gy = fmaxf(fmaxf(ly - qy, qy - hy), 0.f);
+    const float gz = fmaxf(fmaxf(lz - qz, qz - hz), 0.f);
+    return (gx * gx + gy * gy) + gz * gz;
+}
+
 template <class PTR>
 __device__ __forceinline__ int kd_nearest(const MeshDev& M, float qx, float qy, float qz, PTR stk,
                                           uint32_t stride, float& best_out) {
@@ -141,8 +158,13 @@ __device__ __forceinline__ int kd_nearest(const MeshDev& M, float qx, float qy, 
     uint32_t cur = M.kd_root;
     int sp = 0;
     for (;;) {
+        bool near_skipped = false;
         while (!(cur & KD_LEAF)) {
             const uint4 nd = M.kd_nodes[cur];
+            const float4* bx4 = (const float4*)(M.kd_boxes + 16 * (size_t)cur);
+            const float4 bA = bx4[0], bB = bx4[1], bC = bx4[2];
+            const float lbc1 = box_lb(qx, qy, qz, bA.x, bA.y, bA.z, bA.w, bB.x, bB.y);
+            const float lbc2 = box_lb(qx, qy, qz, bB.z, bB.w, bC.x, bC.y, bC.z, bC.w);
             const float divlow = __uint_as_float(nd.x), divhigh = __uint_as_float(nd.y);
             const uint32_t feat = (nd.z >> sdfk::KD_FEAT_SHIFT) & 3u;
             const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
@@ -154,13 +176,19 @@ __device__ __forceinline__ int kd_nearest(const MeshDev& M, float qx, float qy, 
             const float cut = (val - pl) * (val - pl);
             const float dst = feat == 0 ? d0 : (feat == 1 ? d1 : d2);
             const float m2 = (mind + cut) - dst;  // nanoflann.hpp:1397
-            stk[(sp * 3 + 0) * stride] = farc | (feat << sdfk::KD_FEAT_SHIFT);
-            stk[(sp * 3 + 1) * stride] = __float_as_uint(m2);
-            stk[(sp * 3 + 2) * stride] = __float_as_uint(cut);
-            ++sp;
+            if ((lowside ? lbc2 : lbc1) < best) {  // far subtree could still matter
+                stk[(sp * 3 + 0) * stride] = farc | (feat << sdfk::KD_FEAT_SHIFT);
+                stk[(sp * 3 + 1) * stride] = __float_as_uint(m2);
+                stk[(sp * 3 + 2) * stride] = __float_as_uint(cut);
+                ++sp;
+            }
+            if (!((lowside ? lbc1 : lbc2) < best)) {  // near subtree is a no-op
+                near_skipped = true;
+                break;
+            }
             cur = lowside ? r1 : r2;
         }
-        {  // leaf (nanoflann.hpp:1350-1367); metric ((0+dx^2)+dy^2)+dz^2 (432-440)
+        if (!near_skipped) {  // leaf (nanoflann.hpp:1350-1367); metric ((0+dx^2)+dy^2)+dz^2 (432-440)
             const uint32_t left = (cur & sdfk::KD_REF_MASK) >> 4, cnt = cur & 15u;
             const float* p = M.kd_pts + 3 * (size_t)left;
             for (uint32_t k = 0; k < cnt; ++k) {
@@ -316,9 +344,10 @@ __device__ __forceinline__ float raycast(const MeshDev& M, V3 p, int* detail) {
 enum { Q_NN = 0, Q_CONTAINS = 1, Q_SDF = 2, Q_DETAIL = 3 };
 
 // Impl::calc per-point body after the sign (sdf.cpp:112-153)
-template <bool ROBUST, class PTR>
-__device__ __forceinline__ float calc_point(const MeshDev& M, V3 p, bool trunc_aabb, float sign,
-                                            PTR stk, uint32_t stride) {
+// `pos` = position of the nearest vertex in tree order (-1: none)
+template <bool ROBUST>
+__device__ __forceinline__ float calc_tail(const MeshDev& M, V3 p, bool trunc_aabb, float sign,
+                                           int pos) {
     const float DIST_EPS = ROBUST ? 0.f : 1e-5f;
     float min_dist = FLT_MAX;
     if (trunc_aabb) {
@@ -327,8 +356,6 @@ __device__ __forceinline__ float calc_point(const MeshDev& M, V3 p, bool trunc_a
             p.z > M.bb[5])
             min_dist = -FLT_MAX;
     }
-    float bestd;
-    const int pos = kd_nearest(M, p.x, p.y, p.z, stk, stride, bestd);
     V3 avg = {0.f, 0.f, 0.f};
     V3 vnn = {0.f, 0.f, 0.f};
     if (pos >= 0) {
@@ -361,15 +388,35 @@ __device__ __forceinline__ float calc_point(const MeshDev& M, V3 p, bool trunc_a
     return min_dist;
 }
 
+template <bool ROBUST, class PTR>
+__device__ __forceinline__ float calc_point(const MeshDev& M, V3 p, bool trunc_aabb, float sign,
+                                            PTR stk, uint32_t stride) {
+    float bestd;
+    const int pos = kd_nearest(M, p.x, p.y, p.z, stk, stride, bestd);
+    return calc_tail<ROBUST>(M, p, trunc_aabb, sign, pos);
+}
+
 template <int KIND, bool ROBUST, bool GSTACK>
 __global__ __launch_bounds__(QBLOCK) void k_query(MeshDev M, const float* __restrict__ pts,
                                                   const uint32_t* __restrict__ perm, int64_t n,
                                                   int trunc_aabb, void* __restrict__ out,
-                                                  uint32_t* gstack, uint32_t depth_cap) {
+                                                  uint32_t* gstack, uint32_t depth_cap,
+                                                  const uint32_t* __restrict__ n_dev) {
     extern __shared__ uint32_t lds[];
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (int64_t i = tid; i < n; i += nthreads) {
+    int64_t first = tid, step = nthreads;
+    if (n_dev) {
+        // deferred near-tie queries of the packet kernel: the count lives on the device.  These
+        // queries are sparse (incoherent) and some are very long (symmetric spots with hundreds
+        // of near-equidistant vertices), so only every 4th lane takes one: less divergence
+        // serialisation per wave, and the launch is tail-latency bound anyway.
+        n = (int64_t)*n_dev;
+        if (tid & 3) return;
+        first = tid >> 2;
+        step = nthreads >> 2;
+    }
+    for (int64_t i = first; i < n; i += step) {
         const int64_t src = perm ? (int64_t)perm[i] : i;
         const V3 p = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
         if (KIND == Q_NN) {
@@ -406,6 +453,260 @@ __global__ __launch_bounds__(QBLOCK) void k_query(MeshDev M, const float* __rest
                 ((float*)out)[src] = v;
         }
     }
+}
+
+
+// =========================================================================================
+// Packet nearest-vertex search: one WAVE walks the kd-tree for 64 Morton-adjacent queries.
+//
+// Far-field queries make nanoflann's per-query search visit ~100 leaves / ~500 vertices, and
+// 64 independent lanes doing that diverge badly (29 % VALU lane utilisation measured).  Here
+// the traversal is wave-uniform: the node stream is read with scalar loads, the stack is one
+// small LDS array per wave, every lane evaluates every visited vertex (no divergence).  A
+// subtree is skipped only when, for every lane, the tight box of its vertices is farther
+// than the lane's current best * c:  LB = ((gx^2+gy^2)+gz^2) with g = per-axis gap to the
+// box is a rigorous lower bound of every computed vertex distance in that box (rounding is
+// monotone and the association equals the metric's, nanoflann.hpp:432-440).
+//
+// What this pass knows exactly per lane when it ends: the global fp32 minimum `best`, its
+// (first found) vertex `holder`, and `second` = the smallest distance found that is >= best
+// among all OTHER vertices whose distance is <= best * c.
+//
+// Equivalence with nanoflann (DESIGN.md "nn: packet pass + strict fallback"): nanoflann prunes
+// a far subtree S iff mindistsq(S) > worst (nanoflann.hpp:1399).  mindistsq(S) is an fp32
+// chain that never exceeds dist(p) * (1 + w_th) for any vertex p in S, with
+// w_th = 2^-24 * (3.02 * depth + 11.2).  With c >= (1 + w_th) / (1 - 2^-24): if no other
+// vertex lies within best * c (second > best * c), the unique minimiser cannot be pruned
+// before it is visited and no other vertex can tie or beat it, so nanoflann returns `holder`.
+// Otherwise (exact ties, near ties within ~5e-6 relative, underflow-range distances, NaNs)
+// the query is "ambiguous" and is appended to a fallback list that the strict per-lane
+// kernel (kd_nearest: exact emulation) processes afterwards.  Parity is by construction.
+// =========================================================================================
+constexpr int PBLOCK = 256;
+
+
+// result of the packet pass for one lane
+struct PacketBest {
+    float b;  // global fp32 minimum over all vertices
+    float s;  // second smallest distance as a multiset (an exact tie shows as s == b); exact
+              // whenever it is <= b * c^2
+    int h;    // among the vertices at distance exactly b: the one nanoflann's near-first DFS
+              // (for THIS lane) meets first
+};
+
+// Which of two exact-minimum vertices does nanoflann meet first?  The packet walks the tree in
+// one wave-uniform order, so when a later leaf ties the current holder, their lowest common
+// ancestor is a node of the current root-to-leaf path: the shallowest node through which the
+// walk has turned since the holder was set (`lca`, 64 = still the holder's own leaf).  There
+// the packet took child X (holder's side) first; nanoflann for this lane takes its own near
+// child first (nanoflann.hpp:1379-1390), recorded per path level in `nearbits` (bit D set =
+// the lane's near child at the level-D node is the child the packet took first).  Inside one
+// leaf the lower position comes first (nanoflann.hpp:1354) and positions are walked ascending.
+__device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, bool valid, float qx, float qy,
+                                                        float qz, uint32_t* stk) {
+    float b = FLT_MAX, s2 = FLT_MAX;
+    int h = -1;
+    int lca = 64;
+    uint32_t near_lo = 0, near_hi = 0;  // nearbits, levels 0-31 / 32-63
+    const float c = M.amb_c2;           // everything within best * c^2 is evaluated
+    uint32_t cur = M.kd_root;
+    uint32_t level = 0;  // depth of `cur` (root = 0), wave-uniform
+    int sp = 0;
+    for (;;) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        level = __builtin_amdgcn_readfirstlane(level);
+        bool need_pop = false;
+        if (!(cur & KD_LEAF)) {
+            const uint4 nd = M.kd_nodes[cur];
+            const float* bx = M.kd_boxes + 16 * (size_t)cur;
+            const float thr = b * c;
+            const float lb1 = box_lb(qx, qy, qz, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]);
+            const float lb2 = box_lb(qx, qy, qz, bx[6], bx[7], bx[8], bx[9], bx[10], bx[11]);
+            const bool a1 = __ballot(valid && lb1 <= thr) != 0ull;
+            const bool a2 = __ballot(valid && lb2 <= thr) != 0ull;
+            const uint32_t r1 = nd.z & ~KD_FEATM, r2 = nd.w;
+            if (a1 && a2) {
+                // order: the child most lanes call "near" (nanoflann.hpp:1371-1387)
+                const uint32_t feat = (nd.z >> sdfk::KD_FEAT_SHIFT) & 3u;
+                const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
+                const float divlow = __uint_as_float(nd.x), divhigh = __uint_as_float(nd.y);
+                const bool lowside = ((val - divlow) + (val - divhigh)) < 0;
+                const int votes = __popcll(__ballot(valid && lowside));
+                const int nval = __popcll(__ballot(valid));
+                const bool first1 = 2 * votes >= nval;
+                const uint32_t bit = (lowside == first1) ? 1u : 0u;
+                if (level < 32u)
+                    near_lo = (near_lo & ~(1u << level)) | (bit << level);
+                else
+                    near_hi = (near_hi & ~(1u << (level - 32u))) | (bit << (level - 32u));
+                stk[2 * sp] = (cur << 1) | (first1 ? 1u : 0u);  // deferred child: 1 = child2
+                stk[2 * sp + 1] = level;
+                ++sp;
+                cur = first1 ? r1 : r2;
+                ++level;
+            } else if (a1) {
+                cur = r1;
+                ++level;
+            } else if (a2) {
+                cur = r2;
+                ++level;
+            } else {
+                need_pop = true;
+            }
+        } else {
+            const uint32_t left = (cur & sdfk::KD_REF_MASK) >> 4, cnt = cur & 15u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float4 P = M.kd_pts4[left + k];
+                const float dx = qx - P.x, dy = qy - P.y, dz = qz - P.z;
+                const float dist = (dx * dx + dy * dy) + dz * dz;  // the metric's association
+                const int idx = (int)(left + k);
+                if (__ballot(dist == b) != 0ull) {  // rare: exact tie with the current minimum
+                    if (dist == b && lca != 64) {
+                        const uint32_t bits = lca < 32 ? near_lo >> lca : near_hi >> (lca - 32);
+                        if (!(bits & 1u)) {  // the lane's near child is the one the packet took second
+                            h = idx;
+                            lca = 64;
+                        }
+                    }
+                }
+                s2 = fminf(s2, fmaxf(dist, b));
+                if (dist < b) {
+                    b = dist;
+                    h = idx;
+                    lca = 64;
+                }
+            }
+            need_pop = true;
+        }
+        if (need_pop) {
+            for (;;) {
+                if (sp == 0) return PacketBest{b, s2, h};
+                --sp;
+                const uint32_t e = __builtin_amdgcn_readfirstlane(stk[2 * sp]);
+                const uint32_t plevel = __builtin_amdgcn_readfirstlane(stk[2 * sp + 1]);
+                lca = min(lca, (int)plevel);  // the walk turns at this node
+                const uint32_t parent = e >> 1, which = e & 1u;
+                const float* bx = M.kd_boxes + 16 * (size_t)parent + 6 * which;
+                const float lb = box_lb(qx, qy, qz, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]);
+                if (__ballot(valid && lb <= b * c) != 0ull) {
+                    const uint4 nd = M.kd_nodes[parent];
+                    cur = which ? nd.w : (nd.z & ~KD_FEATM);
+                    level = plevel + 1;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+// Largest mindistsq' that nanoflann tests on its way to the leaf holding tree position `pos`
+// (one value per far descent on that path, nanoflann.hpp:1396-1399), computed with the same
+// mindistsq / dists[] arithmetic as kd_nearest.  If every one of them is <= the smallest
+// distance any OTHER vertex has, none of those tests can fail whatever was visited before
+// (worst >= that distance until `pos` itself is evaluated), so `pos` is certainly visited.
+__device__ __forceinline__ float kd_path_max_bound(const MeshDev& M, float qx, float qy, float qz,
+                                                   int pos) {
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, mind = 0.f;
+    if (qx < M.bb[0]) { d0 = (qx - M.bb[0]) * (qx - M.bb[0]); mind += d0; }
+    if (qx > M.bb[3]) { d0 = (qx - M.bb[3]) * (qx - M.bb[3]); mind += d0; }
+    if (qy < M.bb[1]) { d1 = (qy - M.bb[1]) * (qy - M.bb[1]); mind += d1; }
+    if (qy > M.bb[4]) { d1 = (qy - M.bb[4]) * (qy - M.bb[4]); mind += d1; }
+    if (qz < M.bb[2]) { d2 = (qz - M.bb[2]) * (qz - M.bb[2]); mind += d2; }
+    if (qz > M.bb[5]) { d2 = (qz - M.bb[5]) * (qz - M.bb[5]); mind += d2; }
+    float worst_bound = 0.f;
+    uint32_t cur = M.kd_root;
+    while (!(cur & KD_LEAF)) {
+        const uint4 nd = M.kd_nodes[cur];
+        const uint32_t split = __float_as_uint(M.kd_boxes[16 * (size_t)cur + 12]);
+        const float divlow = __uint_as_float(nd.x), divhigh = __uint_as_float(nd.y);
+        const uint32_t feat = (nd.z >> sdfk::KD_FEAT_SHIFT) & 3u;
+        const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
+        const bool lowside = ((val - divlow) + (val - divhigh)) < 0;  // near child is child 1
+        const bool in1 = (uint32_t)pos < split;
+        if (in1 != lowside) {  // far descent
+            const float pl = lowside ? divhigh : divlow;
+            const float cut = (val - pl) * (val - pl);
+            const float dst = feat == 0 ? d0 : (feat == 1 ? d1 : d2);
+            const float m2 = (mind + cut) - dst;
+            if (!(m2 <= worst_bound)) worst_bound = m2;  // NaN propagates as "too large"
+            mind = m2;
+            if (feat == 0) d0 = cut; else if (feat == 1) d1 = cut; else d2 = cut;
+        }
+        cur = in1 ? (nd.z & ~KD_FEATM) : nd.w;
+    }
+    return worst_bound;
+}
+
+template <int KIND, bool ROBUST>
+__global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float* __restrict__ pts,
+                                                         const uint32_t* __restrict__ perm, int64_t n,
+                                                         int trunc_aabb, void* __restrict__ out,
+                                                         unsigned long long* __restrict__ amb_mask,
+                                                         uint32_t* __restrict__ amb_cnt,
+                                                         uint32_t depth_cap) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* stk = lds + (threadIdx.x >> 6) * 2 * (depth_cap + 1);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    const int64_t src = valid ? (perm ? (int64_t)perm[i] : i) : 0;
+    V3 p = {0.f, 0.f, 0.f};
+    if (valid) p = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
+    float sign = 0.f;
+    if (ROBUST && KIND != Q_NN && valid) sign = raycast(M, p, nullptr);  // sdf.cpp:110
+    const PacketBest pb = kd_nearest_packet(M, valid, p.x, p.y, p.z, stk);
+    // pb.h is nanoflann's answer iff nanoflann does not prune it before visiting it:
+    //  (1) no other vertex within b * c (c - 1 ~ 4.5e-6): impossible, see k_query_packet header;
+    //  (2) otherwise measure it: every bound tested on the way to pb.h is <= the distance of
+    //      any other vertex (>= pb.s; == b for an exact tie, where pb.h is the first met);
+    //  (3) else defer to the strict kernel (exact emulation).
+    const int pos = pb.h;
+    bool amb = false;
+    if (valid && (!(pb.s > pb.b * M.amb_c) || !(pb.b >= 1e-30f))) {
+        amb = true;
+        if (pb.h >= 0 && pb.b < FLT_MAX) {
+            const float mb = kd_path_max_bound(M, p.x, p.y, p.z, pb.h);
+            amb = !(mb <= pb.s);
+        }
+    }
+    if (pb.h < 0) amb = true;
+    {   // ambiguous lanes of this wave, in sorted order: compacted (stably) by k_fb_compact so
+        // that the strict fallback kernel still sees Morton-coherent waves
+        const unsigned long long m = __ballot(valid && amb);
+        if ((threadIdx.x & 63) == 0) {
+            amb_mask[i >> 6] = m;
+            amb_cnt[i >> 6] = (uint32_t)__popcll(m);
+        }
+    }
+    if (!valid || amb) return;
+    if (KIND == Q_NN) {
+        ((int32_t*)out)[src] = M.kd_vind[pos];
+    } else {
+        const bool trunc = (KIND == Q_CONTAINS) ? true : (trunc_aabb != 0);
+        const float v = calc_tail<ROBUST>(M, p, trunc, sign, pos);
+        if (KIND == Q_CONTAINS)
+            ((uint8_t*)out)[src] = v >= 0;
+        else
+            ((float*)out)[src] = v;
+    }
+}
+
+
+// amb_cnt has been exclusive-scanned: wave w's ambiguous queries go to fb_list[amb_cnt[w] ...]
+// The list accumulates over the chunks of one call (entries are absolute point indices):
+// *base_in = entries already in the list, *total_out (a different word) = new total.
+__global__ void k_fb_compact(const unsigned long long* __restrict__ amb_mask,
+                             const uint32_t* __restrict__ amb_scan, const uint32_t* __restrict__ perm,
+                             int64_t n, uint32_t off, uint32_t* __restrict__ fb_list,
+                             const uint32_t* __restrict__ base_in, uint32_t* __restrict__ total_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t w = i >> 6;
+    const int lane = (int)(i & 63);
+    const unsigned long long m = amb_mask[w];
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t base = *base_in + amb_scan[w];
+    if ((m >> lane) & 1ull) fb_list[base + (uint32_t)__popcll(m & lt)] = off + perm[i];
+    if (i == n - 1) *total_out = base + (uint32_t)__popcll(m);
 }
 
 // =========================================================================================
@@ -510,6 +811,22 @@ __global__ void k_scan_add(uint32_t* __restrict__ data, uint32_t n, const uint32
     if (i < n) data[i] += sums[i / 2048u];
 }
 
+// in-place exclusive scan of n u32 (n <= 2048^3); s1/s2 hold ceil(n/2048) and ceil(n/2048^2) sums
+static int exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* s1, uint32_t* s2, hipStream_t s) {
+    if (n == 0) return 0;
+    const uint32_t n1 = (n + 2047) / 2048, n2 = (n1 + 2047) / 2048;
+    k_scan_block<<<n1, 256, 0, s>>>(data, n, s1);
+    if (n1 > 1) {
+        k_scan_block<<<n2, 256, 0, s>>>(s1, n1, s2);
+        if (n2 > 1) {
+            k_scan_block<<<1, 256, 0, s>>>(s2, n2, nullptr);
+            k_scan_add<<<(n1 + 255) / 256, 256, 0, s>>>(s1, n1, s2);
+        }
+        k_scan_add<<<(n + 255) / 256, 256, 0, s>>>(data, n, s1);
+    }
+    return 0;
+}
+
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift,
@@ -603,15 +920,7 @@ struct RadixSorter {
         for (int p = 0; p < passes; ++p) {
             const int shift = 8 * p;
             k_rs_hist<<<ntiles, RS_THREADS, 0, s>>>(ki, n, shift, hist, ntiles);
-            k_scan_block<<<n1, 256, 0, s>>>(hist, nh, sums1);
-            if (n1 > 1) {
-                k_scan_block<<<n2, 256, 0, s>>>(sums1, n1, sums2);
-                if (n2 > 1) {
-                    k_scan_block<<<1, 256, 0, s>>>(sums2, n2, nullptr);
-                    k_scan_add<<<(n1 + 255) / 256, 256, 0, s>>>(sums1, n1, sums2);
-                }
-                k_scan_add<<<(nh + 255) / 256, 256, 0, s>>>(hist, nh, sums1);
-            }
+            exclusive_scan_u32(hist, nh, sums1, sums2, s);
             k_rs_scatter<<<ntiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, hist, ntiles,
                                                        (p == 0 && iota) ? 1 : 0);
             uint32_t* t = ki;
@@ -851,6 +1160,18 @@ struct sdfhip_ctx {
     float* d_kd_pts = nullptr;
     int32_t* d_kd_vind = nullptr;
     size_t kd_nodes_cap = 0;
+    float* d_kd_boxes = nullptr;
+    float4* d_kd_pts4 = nullptr;
+    float amb_c = 1.f, amb_c2 = 1.f;
+    uint32_t* d_fb_list = nullptr;
+    uint32_t* d_fb_count = nullptr;  // two words, ping-pong (see k_fb_compact)
+    int64_t fb_cap = 0;
+    uint32_t last_fb = 0;  // length of the last deferred list (read back only while profiling)
+    unsigned long long* d_amb_mask = nullptr;
+    uint32_t* d_amb_cnt = nullptr;
+    uint32_t* d_amb_s1 = nullptr;
+    uint32_t* d_amb_s2 = nullptr;
+    int64_t opt_packet = 1;
     uint32_t* d_adj_off = nullptr;
     int32_t* d_adj_faces = nullptr;
     float4* d_geo = nullptr;
@@ -1002,14 +1323,28 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
         return fail(SDFHIP_E_INVALID, "kd-tree too large");
     if (h->kd.nodes.size() > h->kd_nodes_cap) {
         if (int rc = dalloc(&h->d_kd_nodes, h->kd.nodes.size())) return rc;
+        if (int rc = dalloc(&h->d_kd_boxes, 16 * h->kd.nodes.size())) return rc;
         h->kd_nodes_cap = h->kd.nodes.size();
+    }
+    {   // ambiguity factor of the packet pass: c = (1 + w_th + 4u) rounded up, w_th = u(3.02 D + 11.2)
+        const double u = 5.9604644775390625e-8;
+        const double w = u * (3.02 * (double)(h->kd.depth > 0 ? h->kd.depth : 1) + 11.2) + 4.0 * u;
+        float c = (float)(1.0 + w);
+        if ((double)c < 1.0 + w) c = std::nextafter(c, 2.0f);
+        h->amb_c = c;
+        float c2 = (float)((double)c * (double)c * (1.0 + 4.0 * u));
+        if ((double)c2 < (double)c * (double)c * (1.0 + 4.0 * u)) c2 = std::nextafter(c2, 2.0f);
+        h->amb_c2 = c2;
     }
     // points in tree order
     std::vector<float> perm_pts(3 * (size_t)h->nv);
+    std::vector<float> perm_pts4(4 * ((size_t)h->nv + 4), 0.f);
     for (uint32_t i = 0; i < h->nv; ++i) {
         const float* src = h->h_verts + 3 * (size_t)h->kd.vind[i];
         perm_pts[3 * (size_t)i] = src[0], perm_pts[3 * (size_t)i + 1] = src[1];
         perm_pts[3 * (size_t)i + 2] = src[2];
+        perm_pts4[4 * (size_t)i] = src[0], perm_pts4[4 * (size_t)i + 1] = src[1];
+        perm_pts4[4 * (size_t)i + 2] = src[2];
     }
     if (h->nv) {
         HIPC(hipMemcpyAsync(h->d_verts, h->h_verts, sizeof(float) * 3 * (size_t)h->nv,
@@ -1019,9 +1354,14 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
         HIPC(hipMemcpyAsync(h->d_kd_vind, h->kd.vind.data(), sizeof(int32_t) * (size_t)h->nv,
                             hipMemcpyHostToDevice, s));
     }
-    if (!h->kd.nodes.empty())
+    HIPC(hipMemcpyAsync(h->d_kd_pts4, perm_pts4.data(), sizeof(float) * perm_pts4.size(),
+                        hipMemcpyHostToDevice, s));
+    if (!h->kd.nodes.empty()) {
         HIPC(hipMemcpyAsync(h->d_kd_nodes, h->kd.nodes.data(), sizeof(uint4) * h->kd.nodes.size(),
                             hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(h->d_kd_boxes, h->kd.boxes.data(), sizeof(float) * 16 * h->kd.boxes.size(),
+                            hipMemcpyHostToDevice, s));
+    }
     HIPC(hipStreamSynchronize(s));  // perm_pts is pageable and about to go out of scope
     if (h->robust && draw_R && !h->R_pinned) draw_rotation(h);
     if (int rc = update_device_side(h)) return rc;
@@ -1038,6 +1378,10 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.kd_vind = h->d_kd_vind;
     M.kd_root = h->kd.root_ref;
     for (int d = 0; d < 6; ++d) M.bb[d] = h->aabb[d];
+    M.kd_boxes = h->d_kd_boxes;
+    M.kd_pts4 = h->d_kd_pts4;
+    M.amb_c = h->amb_c;
+    M.amb_c2 = h->amb_c2;
     M.adj_off = h->d_adj_off;
     M.adj_faces = h->d_adj_faces;
     M.geo = h->d_geo;
@@ -1048,22 +1392,13 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     return M;
 }
 
+// strict per-lane kernel (exact nanoflann emulation).  n_dev != nullptr: the point count is read
+// from device memory (fallback list of the packet kernel) and `n` only sizes the grid.
 template <int KIND, bool ROBUST>
-int launch_query(sdfhip_ctx* h, const MeshDev& M, const float* d_pts, const uint32_t* perm, int64_t n,
-                 int trunc, void* d_out, hipStream_t s) {
+int launch_strict(sdfhip_ctx* h, const MeshDev& M, const float* d_pts, const uint32_t* perm, int64_t n,
+                  int trunc, void* d_out, const uint32_t* n_dev, hipStream_t s) {
     const bool needs_kd = !(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST));
     const uint32_t depth = (uint32_t)(h->kd.depth > 0 ? h->kd.depth : 1);
-    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    if (h->opt_profile && h->prof_pending.size() < 8192) {
-        if (!h->prof_free.empty()) {
-            ev = h->prof_free.back();
-            h->prof_free.pop_back();
-        } else {
-            HIPC(hipEventCreate(&ev.first));
-            HIPC(hipEventCreate(&ev.second));
-        }
-        HIPC(hipEventRecord(ev.first, s));
-    }
     const int64_t blocks_full = (n + QBLOCK - 1) / QBLOCK;
     if (needs_kd && depth > (uint32_t)LDS_DEPTH_MAX) {
         const int64_t blocks = blocks_full < 4096 ? blocks_full : 4096;
@@ -1073,48 +1408,106 @@ int launch_query(sdfhip_ctx* h, const MeshDev& M, const float* d_pts, const uint
             h->gstack_words = words;
         }
         k_query<KIND, ROBUST, true><<<(uint32_t)blocks, QBLOCK, 0, s>>>(M, d_pts, perm, n, trunc, d_out,
-                                                                        h->d_gstack, depth);
+                                                                        h->d_gstack, depth, n_dev);
     } else {
         const size_t lds = needs_kd ? (size_t)(QBLOCK / 64) * depth * 192 * sizeof(uint32_t) : 0;
         const int64_t blocks = blocks_full < 0x7FFFFFFF ? blocks_full : 0x7FFFFFFF;
         k_query<KIND, ROBUST, false><<<(uint32_t)blocks, QBLOCK, lds, s>>>(M, d_pts, perm, n, trunc,
-                                                                           d_out, nullptr, depth);
-    }
-    if (ev.first) {
-        HIPC(hipEventRecord(ev.second, s));
-        h->prof_pending.push_back(ev);
-        h->prof_points += n;
+                                                                           d_out, nullptr, depth, n_dev);
     }
     HIPC(hipGetLastError());
     return 0;
 }
 
-int reserve_query_ws(sdfhip_ctx* h, int64_t n) {
-    if (n <= h->q_cap) return 0;
-    if (int rc = dalloc(&h->d_qkeys, (size_t)n)) return rc;
-    if (int rc = dalloc(&h->d_qperm, (size_t)n)) return rc;
-    if (!h->d_qbounds)
-        if (int rc = dalloc(&h->d_qbounds, 8)) return rc;
-    h->q_cap = n;
+struct ProfScope {  // optional hipEvent pair around everything one query call launches
+    sdfhip_ctx* h;
+    hipStream_t s;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    int begin() {
+        if (h->opt_profile && h->prof_pending.size() < 8192) {
+            if (!h->prof_free.empty()) {
+                ev = h->prof_free.back();
+                h->prof_free.pop_back();
+            } else {
+                HIPC(hipEventCreate(&ev.first));
+                HIPC(hipEventCreate(&ev.second));
+            }
+            HIPC(hipEventRecord(ev.first, s));
+        }
+        return 0;
+    }
+    int end(int64_t n) {
+        if (ev.first) {
+            HIPC(hipEventRecord(ev.second, s));
+            h->prof_pending.push_back(ev);
+            h->prof_points += n;
+        }
+        return 0;
+    }
+};
+
+int reserve_query_ws(sdfhip_ctx* h, int64_t n, int64_t fb_cap) {
+    if (n > h->q_cap) {
+        if (int rc = dalloc(&h->d_qkeys, (size_t)n)) return rc;
+        if (int rc = dalloc(&h->d_qperm, (size_t)n)) return rc;
+        const size_t nw = ((size_t)n + 63) / 64 + 4;
+        if (int rc = dalloc(&h->d_amb_mask, nw)) return rc;
+        if (int rc = dalloc(&h->d_amb_cnt, nw)) return rc;
+        if (int rc = dalloc(&h->d_amb_s1, nw / 2048 + 4)) return rc;
+        if (int rc = dalloc(&h->d_amb_s2, nw / 2048 / 2048 + 4)) return rc;
+        if (!h->d_qbounds)
+            if (int rc = dalloc(&h->d_qbounds, 8)) return rc;
+        h->q_cap = n;
+    }
+    if (fb_cap > h->fb_cap) {
+        if (int rc = dalloc(&h->d_fb_list, (size_t)fb_cap)) return rc;
+        h->fb_cap = fb_cap;
+    }
     return 0;
 }
 
-// the whole query path on device pointers; out element size depends on kind
-int run_query(sdfhip_ctx* h, int kind, const float* d_pts, int64_t n, int trunc, void* d_out,
-              hipStream_t s) {
-    if (n < 0) return fail(SDFHIP_E_INVALID, "negative point count");
-    if (n == 0) return 0;
-    if (!d_pts || !d_out) return fail(SDFHIP_E_INVALID, "null points/output pointer");
+// The whole query path on device pointers, one (KIND, ROBUST) instantiation.
+//   per chunk:  [bounds -> Morton keys -> radix sort]  ->  packet kernel (nn for 64 coherent
+//   queries per wave + per-lane ray parity / face distances)  ->  scan + stable compaction of
+//   the deferred near-tie queries into one list for the whole call
+//   at the end (or when the list could overflow): strict kernel over the deferred list.
+// Small / unsorted batches go straight to the strict kernel.
+template <int KIND, bool ROBUST>
+int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d_out, hipStream_t s) {
     const MeshDev M = mesh_view(h);
-    const size_t osz = kind == Q_CONTAINS ? 1 : (kind == Q_DETAIL ? 12 : 4);
+    const size_t osz = KIND == Q_CONTAINS ? 1 : (KIND == Q_DETAIL ? 12 : 4);
     const int64_t chunk = h->opt_chunk > 0 ? h->opt_chunk : (1 << 24);
+    const bool needs_kd = !(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST));
+    const uint32_t depth = (uint32_t)(h->kd.depth > 0 ? h->kd.depth : 1);
+    const bool sort_any = h->opt_sort && n >= h->opt_sort_min;
+    const bool packet_any = sort_any && needs_kd && h->opt_packet && depth < 64;  // nearbits: 64 levels
+    const int64_t fb_cap = packet_any ? (n < (1ll << 27) ? n : (1ll << 27)) : 0;
+    if (sort_any)
+        if (int rc = reserve_query_ws(h, n < chunk ? n : chunk, fb_cap)) return rc;
+    ProfScope prof{h, s};
+    if (int rc = prof.begin()) return rc;
+    int64_t deferred_pts = 0;  // points whose near ties may sit in the deferred list
+    int flip = 0;              // d_fb_count[flip] holds the current list length
+    if (packet_any) HIPC(hipMemsetAsync(h->d_fb_count, 0, 2 * sizeof(uint32_t), s));
+    auto flush = [&]() -> int {
+        if (deferred_pts == 0) return 0;
+        const int64_t grid_pts = deferred_pts < (int64_t)QBLOCK * 4096 ? deferred_pts : (int64_t)QBLOCK * 4096;
+        if (int rc = launch_strict<KIND, ROBUST>(h, M, d_pts, h->d_fb_list, grid_pts, trunc, d_out,
+                                                 h->d_fb_count + flip, s))
+            return rc;
+        if (h->opt_profile)
+            HIPC(hipMemcpyAsync(&h->last_fb, h->d_fb_count + flip, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPC(hipMemsetAsync(h->d_fb_count, 0, 2 * sizeof(uint32_t), s));
+        flip = 0;
+        deferred_pts = 0;
+        return 0;
+    };
     for (int64_t off = 0; off < n; off += chunk) {
         const int64_t m = (n - off) < chunk ? (n - off) : chunk;
         const float* p = d_pts + 3 * off;
         void* o = (char*)d_out + osz * (size_t)off;
         const uint32_t* perm = nullptr;
         if (h->opt_sort && m >= h->opt_sort_min) {
-            if (int rc = reserve_query_ws(h, m)) return rc;
             k_bounds_init<<<1, 64, 0, s>>>(h->d_qbounds);
             const int nb = (int)((m + 255) / 256 < 2048 ? (m + 255) / 256 : 2048);
             k_bounds<<<nb, 256, 0, s>>>(p, m, h->d_qbounds);
@@ -1123,25 +1516,55 @@ int run_query(sdfhip_ctx* h, int kind, const float* d_pts, int64_t n, int trunc,
             if (int rc = h->sorter.sort(h->d_qkeys, h->d_qperm, (uint32_t)m, 30, 1, s)) return rc;
             perm = h->d_qperm;
         }
-        int rc = 0;
-        if (h->robust) {
-            switch (kind) {
-                case Q_NN: rc = launch_query<Q_NN, true>(h, M, p, perm, m, trunc, o, s); break;
-                case Q_CONTAINS: rc = launch_query<Q_CONTAINS, true>(h, M, p, perm, m, trunc, o, s); break;
-                case Q_SDF: rc = launch_query<Q_SDF, true>(h, M, p, perm, m, trunc, o, s); break;
-                case Q_DETAIL: rc = launch_query<Q_DETAIL, true>(h, M, p, perm, m, trunc, o, s); break;
-            }
+        if (perm && packet_any) {
+            if (deferred_pts + m > h->fb_cap)
+                if (int rc = flush()) return rc;
+            const size_t lds = (size_t)(PBLOCK / 64) * 2 * (depth + 1) * sizeof(uint32_t);
+            constexpr int PK = KIND == Q_DETAIL ? Q_NN : KIND;
+            k_query_packet<PK, ROBUST><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, lds, s>>>(
+                M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, depth);
+            exclusive_scan_u32(h->d_amb_cnt, (uint32_t)((m + 63) / 64), h->d_amb_s1, h->d_amb_s2, s);
+            k_fb_compact<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(
+                h->d_amb_mask, h->d_amb_cnt, perm, m, (uint32_t)off, h->d_fb_list, h->d_fb_count + flip,
+                h->d_fb_count + (flip ^ 1));
+            HIPC(hipGetLastError());
+            flip ^= 1;
+            deferred_pts += m;
         } else {
-            switch (kind) {
-                case Q_NN: rc = launch_query<Q_NN, false>(h, M, p, perm, m, trunc, o, s); break;
-                case Q_CONTAINS: rc = launch_query<Q_CONTAINS, false>(h, M, p, perm, m, trunc, o, s); break;
-                case Q_SDF: rc = launch_query<Q_SDF, false>(h, M, p, perm, m, trunc, o, s); break;
-                default: return fail(SDFHIP_E_STATE, "raycast detail needs a robust handle");
-            }
+            if (int rc = launch_strict<KIND, ROBUST>(h, M, p, perm, m, trunc, o, nullptr, s)) return rc;
         }
-        if (rc) return rc;
     }
-    return 0;
+    if (int rc = flush()) return rc;
+    return prof.end(n);
+}
+
+int run_query(sdfhip_ctx* h, int kind, const float* d_pts, int64_t n, int trunc, void* d_out,
+              hipStream_t s) {
+    if (n < 0) return fail(SDFHIP_E_INVALID, "negative point count");
+    if (n == 0) return 0;
+    if (!d_pts || !d_out) return fail(SDFHIP_E_INVALID, "null points/output pointer");
+    if (n > 0xFFFF0000ll) {  // deferred-list entries are 32-bit absolute indices
+        const size_t osz = kind == Q_CONTAINS ? 1 : (kind == Q_DETAIL ? 12 : 4);
+        const int64_t half = 0x80000000ll;
+        if (int rc = run_query(h, kind, d_pts, half, trunc, d_out, s)) return rc;
+        return run_query(h, kind, d_pts + 3 * half, n - half, trunc, (char*)d_out + osz * (size_t)half, s);
+    }
+    if (h->robust) {
+        switch (kind) {
+            case Q_NN: return run_query_t<Q_NN, true>(h, d_pts, n, trunc, d_out, s);
+            case Q_CONTAINS: return run_query_t<Q_CONTAINS, true>(h, d_pts, n, trunc, d_out, s);
+            case Q_SDF: return run_query_t<Q_SDF, true>(h, d_pts, n, trunc, d_out, s);
+            case Q_DETAIL: return run_query_t<Q_DETAIL, true>(h, d_pts, n, trunc, d_out, s);
+        }
+    } else {
+        switch (kind) {
+            case Q_NN: return run_query_t<Q_NN, false>(h, d_pts, n, trunc, d_out, s);
+            case Q_CONTAINS: return run_query_t<Q_CONTAINS, false>(h, d_pts, n, trunc, d_out, s);
+            case Q_SDF: return run_query_t<Q_SDF, false>(h, d_pts, n, trunc, d_out, s);
+            default: return fail(SDFHIP_E_STATE, "raycast detail needs a robust handle");
+        }
+    }
+    return fail(SDFHIP_E_INVALID, "unknown query kind");
 }
 
 // host-pointer entry: stage through device buffers in chunks
@@ -1269,6 +1692,8 @@ int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32
     A(dalloc(&h->d_faces, 3 * (size_t)nf));
     A(dalloc(&h->d_kd_pts, 3 * (size_t)nv));
     A(dalloc(&h->d_kd_vind, (size_t)nv));
+    A(dalloc(&h->d_kd_pts4, (size_t)nv + 4));
+    A(dalloc(&h->d_fb_count, 2));
     A(dalloc(&h->d_adj_off, (size_t)nv + 1));
     A(dalloc(&h->d_adj_faces, 3 * (size_t)nf));
     A(dalloc(&h->d_geo, 4 * (size_t)nf));
@@ -1316,7 +1741,8 @@ void sdfhip_destroy(sdfhip_t* h) {
                     h->d_adj_faces, h->d_geo, h->d_rface, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
-                    h->topo.depthI, h->d_qkeys, h->d_qperm, h->d_qbounds, h->d_gstack};
+                    h->topo.depthI, h->d_qkeys, h->d_qperm, h->d_qbounds, h->d_gstack, h->d_kd_boxes, h->d_kd_pts4,
+                    h->d_fb_list, h->d_fb_count, h->d_amb_mask, h->d_amb_cnt, h->d_amb_s1, h->d_amb_s2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->sorter.release();
@@ -1476,6 +1902,11 @@ int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* o) {
     o->query_kernel_ms = h->prof_ms;
     o->query_kernel_launches = h->prof_launches;
     o->query_kernel_points = h->prof_points;
+    o->last_fallback_points = 0;
+    if (h->d_fb_count) {
+        DevGuard g(h->device);
+        o->last_fallback_points = h->last_fb;
+    }
     return 0;
 }
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
@@ -1487,6 +1918,8 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_profile = v;
         if (v == 2) h->prof_ms = 0.0, h->prof_launches = 0, h->prof_points = 0;  // reset
     }
+    else if (!strcmp(key, "packet"))
+        h->opt_packet = v;
     else if (!strcmp(key, "sort_min"))
         h->opt_sort_min = v;
     else if (!strcmp(key, "chunk")) {

@@ -136,6 +136,56 @@ def test_degenerate_vertex_sets_use_deep_trees():
     assert (s.nn(pts) == o.nn(pts)).all()
 
 
+def test_tie_heavy_lattices_packet_and_strict_paths():
+    """integer-lattice vertices + half-integer / on-vertex queries: up to 8-way exact distance
+    ties, resolved by nanoflann's visiting order.  Large batch -> packet pass (+ tie tracking,
+    path-bound check, deferred strict fallback); small batch / sort off -> strict kernel."""
+    rng = np.random.default_rng(11)
+    g = np.stack(np.meshgrid(*[np.arange(-6, 7)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    v = (g[rng.permutation(g.shape[0])[:1500]] * 0.125).astype(np.float32)
+    v = np.concatenate([v, v[:40]])  # exact duplicates too
+    f = np.array([[0, 1, 2], [3, 4, 5]], np.uint32)
+    o = po.OracleSDF(v, f, False)
+    q = np.concatenate([
+        (rng.integers(-14, 15, (40000, 3)) * 0.0625),          # lattice + half-lattice points
+        rng.uniform(-1, 1, (20000, 3)),
+        v[rng.integers(0, v.shape[0], 5000)],                  # exactly on vertices
+    ]).astype(np.float32)
+    ref = o.nn(q)
+    d = ((v[:, None, :] - q[None, :2000, :]) ** 2).sum(-1)
+    assert ((d == d.min(0, keepdims=True)).sum(0) > 1).mean() > 0.2  # plenty of exact ties
+    s = SDF(v, f, robust=False)
+    s.set_option("profile", 1)
+    assert (s.nn(q) == ref).all()
+    assert same_float(s(q), o(q)).all()
+    s.set_option("packet", 0)
+    assert (s.nn(q) == ref).all()
+    s.set_option("sort_queries", 0)
+    assert (s.nn(q) == ref).all()
+    assert (s.nn(q[:5000]) == ref[:5000]).all()
+
+
+def test_near_tie_queries_on_symmetry_axes():
+    """queries on / near the torus axis and tube-centre circle: hundreds of near-equidistant
+    vertices (the deferred-fallback and path-bound cases of the packet pass)."""
+    v, f = meshes.torus(200, 200)
+    R = meshes.random_rotation(8)
+    o = po.OracleSDF(v, f, True, R)
+    s = SDF(v, f)
+    s.set_raycast_axes(R)
+    rng = np.random.default_rng(3)
+    n = 60000
+    z = rng.uniform(-1, 1, n)
+    axis = np.stack([rng.normal(0, 1e-6, n), rng.normal(0, 1e-6, n), z], 1)
+    axis[: n // 4, :2] = 0
+    ang = rng.uniform(0, 2 * np.pi, n)
+    circ = np.stack([0.7 * np.cos(ang), 0.7 * np.sin(ang), np.zeros(n)], 1) + rng.normal(0, 1e-6, (n, 3))
+    q = np.concatenate([axis, circ]).astype(np.float32)
+    assert (s.nn(q) == o.nn(q)).all()
+    assert same_float(s(q), o(q)).all()
+    assert (s.contains(q) == o.contains(q)).all()
+
+
 def test_device_pointer_entry_points_with_torch():
     import torch
     v, f = meshes.torus(83, 83)

@@ -12,6 +12,7 @@ ap.add_argument("--n", type=int, default=16_000_000)
 ap.add_argument("--grid", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--robust", type=int, default=1)
+ap.add_argument("--only", default="")
 a = ap.parse_args()
 v, f = meshes.torus(a.res, a.res)
 s = sdf_amd.SDF(v, f, robust=bool(a.robust))
@@ -25,9 +26,12 @@ else:
     pts = torch.rand((a.n, 3), device=dev, generator=g).mul_(2).sub_(1)
 n = pts.shape[0]
 print("stats", s.stats)
+s.set_option("profile", 1)
 for name, fn in (("nn", s.nn), ("contains", s.contains), ("sdf", s.__call__)):
+    if a.only and name != a.only:
+        continue
     fn(pts); torch.cuda.synchronize()
     best = 1e9
     for _ in range(a.reps):
         t0 = time.perf_counter(); fn(pts); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-    print(f"{name:9s} {best*1e3:9.2f} ms  {n/best/1e6:9.1f} Mevals/s", flush=True)
+    print(f"{name:9s} {best*1e3:9.2f} ms  {n/best/1e6:9.1f} Mevals/s  fallback {s.stats['last_fallback_points']}", flush=True)
