@@ -66,7 +66,7 @@ def cpu_baseline(v, f, R, seed):
     o(pts, n_threads=threads)
     dt = time.perf_counter() - t0
     rate = n / dt
-    n2 = int(min(max(rate * 12.0, n), 16_000_000))
+    n2 = int(min(max(rate * 15.0, n), 80_000_000))
     if n2 > n:
         pts = rng.uniform(-1, 1, (n2, 3)).astype(np.float32)
         t0 = time.perf_counter()
@@ -160,14 +160,14 @@ def main():
 
     total = n * world * a.steps
     value = total / dt
-    # dominant kernel: k_query<SDF, robust>; algorithmic bytes per launch = 16 B x points/launch
+    # dominant kernel: k_query_packet<SDF, robust>; algorithmic bytes per launch = 16 B x points/launch
     kl = max(1, st["query_kernel_launches"])
     k_ms = st["query_kernel_ms"] / kl
     pts_per_launch = st["query_kernel_points"] / kl
     achieved = BYTES_PER_EVAL * pts_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "k_query<Q_SDF,robust>", "kernel_ms_avg": k_ms,
+                "kernel": "k_query_packet<Q_SDF,robust>", "kernel_ms_avg": k_ms,
                 "points_per_launch": pts_per_launch, "launches": kl,
                 "kernel_share_of_step": st["query_kernel_ms"] / (dt * 1e3)}
     extra = {}

@@ -5,7 +5,8 @@
 // of the reference, CMakeLists.txt:33).  "file:line" citations are into /root/reference.
 //
 // Structures (all resident in HBM, sized to sit in L2 / Infinity Cache):
-//   kd_nodes   16 B / internal node of the strict nanoflann-equivalent vertex kd-tree
+//   kd_pn      64 B / internal node of the strict nanoflann-equivalent vertex kd-tree
+//              (tight child boxes + divlow/divhigh + child refs), kd_split 4 B / node
 //   kd_pts     12 B / vertex, in tree (vind) order: a leaf is a contiguous run
 //   geo        64 B / face: a, b, c, unit normal, area (world frame) for dist_point2tri
 //   rnodes     32 B / node: threaded (stackless, pre-order + skip link) LBVH over the
@@ -68,15 +69,14 @@ struct RayNode {  // 32 B
 constexpr uint32_t NOFACE = 0xFFFFFFFFu;
 
 struct MeshDev {
-    // vertex kd-tree
-    const uint4* kd_nodes;
+    // vertex kd-tree: 64 B nodes {box1 lo/hi, box2 lo/hi, divlow, divhigh, ref1|feat, ref2}
+    const float4* kd_pn;
+    const uint32_t* kd_split;
     const float* kd_pts;
     const int32_t* kd_vind;
     uint32_t kd_root;
     float bb[6];  // mesh AABB == kd root bbox
-    // packet traversal extras: tight child boxes (12 floats / internal node), padded points,
-    // ambiguity factor c = 1 + W (see k_query_packet)
-    const float* kd_boxes;  // 16 dwords / internal node: lo1 hi1 lo2 hi2, split position, pad
+    // packet traversal extras: vertices padded to 16 B, ambiguity factors c = 1 + W and ~c^2
     const float4* kd_pts4;
     float amb_c, amb_c2;
     // adjacency + face geometry
@@ -160,17 +160,17 @@ __device__ __forceinline__ int kd_nearest(const MeshDev& M, float qx, float qy, 
     for (;;) {
         bool near_skipped = false;
         while (!(cur & KD_LEAF)) {
-            const uint4 nd = M.kd_nodes[cur];
-            const float4* bx4 = (const float4*)(M.kd_boxes + 16 * (size_t)cur);
-            const float4 bA = bx4[0], bB = bx4[1], bC = bx4[2];
+            const float4* pn = M.kd_pn + 4 * (size_t)cur;
+            const float4 bA = pn[0], bB = pn[1], bC = pn[2], nf = pn[3];
+            const uint32_t ndz = __float_as_uint(nf.z), ndw = __float_as_uint(nf.w);
             const float lbc1 = box_lb(qx, qy, qz, bA.x, bA.y, bA.z, bA.w, bB.x, bB.y);
             const float lbc2 = box_lb(qx, qy, qz, bB.z, bB.w, bC.x, bC.y, bC.z, bC.w);
-            const float divlow = __uint_as_float(nd.x), divhigh = __uint_as_float(nd.y);
-            const uint32_t feat = (nd.z >> sdfk::KD_FEAT_SHIFT) & 3u;
+            const float divlow = nf.x, divhigh = nf.y;
+            const uint32_t feat = (ndz >> sdfk::KD_FEAT_SHIFT) & 3u;
             const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
             const float diff1 = val - divlow, diff2 = val - divhigh;
             const bool lowside = (diff1 + diff2) < 0;
-            const uint32_t r1 = nd.z & ~KD_FEATM, r2 = nd.w;
+            const uint32_t r1 = ndz & ~KD_FEATM, r2 = ndw;
             const uint32_t farc = lowside ? r2 : r1;
             const float pl = lowside ? divhigh : divlow;
             const float cut = (val - pl) * (val - pl);
@@ -494,104 +494,125 @@ struct PacketBest {
               // (for THIS lane) meets first
 };
 
-// Which of two exact-minimum vertices does nanoflann meet first?  The packet walks the tree in
-// one wave-uniform order, so when a later leaf ties the current holder, their lowest common
-// ancestor is a node of the current root-to-leaf path: the shallowest node through which the
-// walk has turned since the holder was set (`lca`, 64 = still the holder's own leaf).  There
-// the packet took child X (holder's side) first; nanoflann for this lane takes its own near
-// child first (nanoflann.hpp:1379-1390), recorded per path level in `nearbits` (bit D set =
-// the lane's near child at the level-D node is the child the packet took first).  Inside one
-// leaf the lower position comes first (nanoflann.hpp:1354) and positions are walked ascending.
-__device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, bool valid, float qx, float qy,
-                                                        float qz, uint32_t* stk) {
-    float b = FLT_MAX, s2 = FLT_MAX;
-    int h = -1;
-    int lca = 64;
-    uint32_t near_lo = 0, near_hi = 0;  // nearbits, levels 0-31 / 32-63
-    const float c = M.amb_c2;           // everything within best * c^2 is evaluated
+// Which of two tree positions does nanoflann's DFS for query q meet first?  Walk down to the
+// node where they part: nanoflann takes its near child first there (nanoflann.hpp:1379-1390);
+// inside one leaf the lower position comes first (1354).
+__device__ __forceinline__ int kd_dfs_first(const MeshDev& M, float qx, float qy, float qz, int pa,
+                                            int pb) {
     uint32_t cur = M.kd_root;
-    uint32_t level = 0;  // depth of `cur` (root = 0), wave-uniform
+    while (!(cur & KD_LEAF)) {
+        const float4 nf = M.kd_pn[4 * (size_t)cur + 3];
+        const uint32_t split = M.kd_split[cur];
+        const bool a1 = (uint32_t)pa < split, b1 = (uint32_t)pb < split;
+        const uint32_t ndz = __float_as_uint(nf.z);
+        if (a1 != b1) {
+            const uint32_t feat = (ndz >> sdfk::KD_FEAT_SHIFT) & 3u;
+            const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
+            const bool lowside = ((val - nf.x) + (val - nf.y)) < 0;  // near child is child 1
+            return (a1 == lowside) ? pa : pb;
+        }
+        cur = a1 ? (ndz & ~KD_FEATM) : __float_as_uint(nf.w);
+    }
+    return pa < pb ? pa : pb;
+}
+
+// One slot of a leaf.  Distances are non-negative floats (or +inf / NaN), whose bit patterns
+// order like unsigned integers, so the multiset insert into (b, s2) and the strict-improvement
+// update of h run on the integer pipe without NaN canonicalisation.  Sentinel slots have
+// distance +inf and change nothing.
+#define SDFK_PACKET_SLOT(K)                                                        \
+    {                                                                              \
+        const float4 P_ = P[K];                                                    \
+        const float dx_ = qx - P_.x, dy_ = qy - P_.y, dz_ = qz - P_.z;             \
+        const uint32_t du_ = __float_as_uint((dx_ * dx_ + dy_ * dy_) + dz_ * dz_); \
+        s2 = min(s2, max(du_, b));                                                 \
+        if (du_ < b) {                                                             \
+            b = du_;                                                               \
+            h = (int)(left + K);                                                   \
+        }                                                                          \
+    }
+
+__device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float qx, float qy, float qz,
+                                                        uint32_t* stk) {
+    uint32_t b = 0x7F7FFFFFu, s2 = 0x7F7FFFFFu;  // FLT_MAX bits (KNNResultSet::init)
+    int h = -1;
+    const float c = M.amb_c2;  // everything within best * c^2 is evaluated
+    uint32_t cur = M.kd_root;
     int sp = 0;
     for (;;) {
         cur = __builtin_amdgcn_readfirstlane(cur);
-        level = __builtin_amdgcn_readfirstlane(level);
         bool need_pop = false;
         if (!(cur & KD_LEAF)) {
-            const uint4 nd = M.kd_nodes[cur];
-            const float* bx = M.kd_boxes + 16 * (size_t)cur;
-            const float thr = b * c;
-            const float lb1 = box_lb(qx, qy, qz, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]);
-            const float lb2 = box_lb(qx, qy, qz, bx[6], bx[7], bx[8], bx[9], bx[10], bx[11]);
-            const bool a1 = __ballot(valid && lb1 <= thr) != 0ull;
-            const bool a2 = __ballot(valid && lb2 <= thr) != 0ull;
-            const uint32_t r1 = nd.z & ~KD_FEATM, r2 = nd.w;
-            if (a1 && a2) {
+            const float* pn = (const float*)(M.kd_pn + 4 * (size_t)cur);  // 16 dwords, scalar load
+            const float thr = __uint_as_float(b) * c;
+            const float lb1 = box_lb(qx, qy, qz, pn[0], pn[1], pn[2], pn[3], pn[4], pn[5]);
+            const float lb2 = box_lb(qx, qy, qz, pn[6], pn[7], pn[8], pn[9], pn[10], pn[11]);
+            const unsigned long long m1 = __ballot(lb1 <= thr), m2 = __ballot(lb2 <= thr);
+            const uint32_t ndz = __float_as_uint(pn[14]);
+            const uint32_t r1 = ndz & ~KD_FEATM, r2 = __float_as_uint(pn[15]);
+            if (m1 != 0ull && m2 != 0ull) {
                 // order: the child most lanes call "near" (nanoflann.hpp:1371-1387)
-                const uint32_t feat = (nd.z >> sdfk::KD_FEAT_SHIFT) & 3u;
+                const uint32_t feat = (ndz >> sdfk::KD_FEAT_SHIFT) & 3u;
                 const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
-                const float divlow = __uint_as_float(nd.x), divhigh = __uint_as_float(nd.y);
-                const bool lowside = ((val - divlow) + (val - divhigh)) < 0;
-                const int votes = __popcll(__ballot(valid && lowside));
-                const int nval = __popcll(__ballot(valid));
-                const bool first1 = 2 * votes >= nval;
-                const uint32_t bit = (lowside == first1) ? 1u : 0u;
-                if (level < 32u)
-                    near_lo = (near_lo & ~(1u << level)) | (bit << level);
-                else
-                    near_hi = (near_hi & ~(1u << (level - 32u))) | (bit << (level - 32u));
-                stk[2 * sp] = (cur << 1) | (first1 ? 1u : 0u);  // deferred child: 1 = child2
-                stk[2 * sp + 1] = level;
-                ++sp;
+                const bool lowside = ((val - pn[12]) + (val - pn[13])) < 0;
+                const bool first1 = __popcll(__ballot(lowside)) >= 32;
+                stk[sp++] = (cur << 1) | (first1 ? 1u : 0u);  // deferred child: 1 = child2
                 cur = first1 ? r1 : r2;
-                ++level;
-            } else if (a1) {
+            } else if (m1 != 0ull) {
                 cur = r1;
-                ++level;
-            } else if (a2) {
+            } else if (m2 != 0ull) {
                 cur = r2;
-                ++level;
             } else {
                 need_pop = true;
             }
         } else {
             const uint32_t left = (cur & sdfk::KD_REF_MASK) >> 4, cnt = cur & 15u;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const float4 P = M.kd_pts4[left + k];
-                const float dx = qx - P.x, dy = qy - P.y, dz = qz - P.z;
-                const float dist = (dx * dx + dy * dy) + dz * dz;  // the metric's association
-                const int idx = (int)(left + k);
-                if (__ballot(dist == b) != 0ull) {  // rare: exact tie with the current minimum
-                    if (dist == b && lca != 64) {
-                        const uint32_t bits = lca < 32 ? near_lo >> lca : near_hi >> (lca - 32);
-                        if (!(bits & 1u)) {  // the lane's near child is the one the packet took second
-                            h = idx;
-                            lca = 64;
-                        }
+            const float4* P = M.kd_pts4 + left;  // uniform: scalar loads; ten slots always exist
+            const uint32_t b0 = b, s0 = s2;
+            const int h0 = h;
+            SDFK_PACKET_SLOT(0)
+            SDFK_PACKET_SLOT(1)
+            SDFK_PACKET_SLOT(2)
+            SDFK_PACKET_SLOT(3)
+            SDFK_PACKET_SLOT(4)
+            if (cnt > 5u) {
+                SDFK_PACKET_SLOT(5)
+                SDFK_PACKET_SLOT(6)
+                SDFK_PACKET_SLOT(7)
+                SDFK_PACKET_SLOT(8)
+                SDFK_PACKET_SLOT(9)
+            }
+            if (__ballot(s2 == b) != 0ull) {
+                // rare: some lane is in a tied state (second smallest == smallest; b is never
+                // FLT_MAX here once a vertex was seen).  Redo the leaf for the wave in
+                // nanoflann's order and settle each exact tie by DFS order.
+                b = b0, s2 = s0, h = h0;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4 Q = P[k];
+                    const float dx = qx - Q.x, dy = qy - Q.y, dz = qz - Q.z;
+                    const uint32_t du = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+                    const int idx = (int)(left + k);
+                    if (du == b && h >= 0 && !(h >= (int)left && h < idx))  // holder in another leaf
+                        h = kd_dfs_first(M, qx, qy, qz, h, idx);
+                    s2 = min(s2, max(du, b));
+                    if (du < b) {
+                        b = du;
+                        h = idx;
                     }
-                }
-                s2 = fminf(s2, fmaxf(dist, b));
-                if (dist < b) {
-                    b = dist;
-                    h = idx;
-                    lca = 64;
                 }
             }
             need_pop = true;
         }
         if (need_pop) {
             for (;;) {
-                if (sp == 0) return PacketBest{b, s2, h};
-                --sp;
-                const uint32_t e = __builtin_amdgcn_readfirstlane(stk[2 * sp]);
-                const uint32_t plevel = __builtin_amdgcn_readfirstlane(stk[2 * sp + 1]);
-                lca = min(lca, (int)plevel);  // the walk turns at this node
+                if (sp == 0) return PacketBest{__uint_as_float(b), __uint_as_float(s2), h};
+                const uint32_t e = __builtin_amdgcn_readfirstlane(stk[--sp]);
                 const uint32_t parent = e >> 1, which = e & 1u;
-                const float* bx = M.kd_boxes + 16 * (size_t)parent + 6 * which;
+                const float* pn = (const float*)(M.kd_pn + 4 * (size_t)parent);
+                const float* bx = pn + 6 * which;
                 const float lb = box_lb(qx, qy, qz, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]);
-                if (__ballot(valid && lb <= b * c) != 0ull) {
-                    const uint4 nd = M.kd_nodes[parent];
-                    cur = which ? nd.w : (nd.z & ~KD_FEATM);
-                    level = plevel + 1;
+                if (__ballot(lb <= __uint_as_float(b) * c) != 0ull) {
+                    cur = which ? __float_as_uint(pn[15]) : (__float_as_uint(pn[14]) & ~KD_FEATM);
                     break;
                 }
             }
@@ -616,10 +637,11 @@ __device__ __forceinline__ float kd_path_max_bound(const MeshDev& M, float qx, f
     float worst_bound = 0.f;
     uint32_t cur = M.kd_root;
     while (!(cur & KD_LEAF)) {
-        const uint4 nd = M.kd_nodes[cur];
-        const uint32_t split = __float_as_uint(M.kd_boxes[16 * (size_t)cur + 12]);
-        const float divlow = __uint_as_float(nd.x), divhigh = __uint_as_float(nd.y);
-        const uint32_t feat = (nd.z >> sdfk::KD_FEAT_SHIFT) & 3u;
+        const float4 nf = M.kd_pn[4 * (size_t)cur + 3];
+        const uint32_t split = M.kd_split[cur];
+        const float divlow = nf.x, divhigh = nf.y;
+        const uint32_t ndz = __float_as_uint(nf.z);
+        const uint32_t feat = (ndz >> sdfk::KD_FEAT_SHIFT) & 3u;
         const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
         const bool lowside = ((val - divlow) + (val - divhigh)) < 0;  // near child is child 1
         const bool in1 = (uint32_t)pos < split;
@@ -632,7 +654,7 @@ __device__ __forceinline__ float kd_path_max_bound(const MeshDev& M, float qx, f
             mind = m2;
             if (feat == 0) d0 = cut; else if (feat == 1) d1 = cut; else d2 = cut;
         }
-        cur = in1 ? (nd.z & ~KD_FEATM) : nd.w;
+        cur = in1 ? (ndz & ~KD_FEATM) : __float_as_uint(nf.w);
     }
     return worst_bound;
 }
@@ -645,15 +667,17 @@ __global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float*
                                                          uint32_t* __restrict__ amb_cnt,
                                                          uint32_t depth_cap) {
     extern __shared__ uint32_t lds[];
-    uint32_t* stk = lds + (threadIdx.x >> 6) * 2 * (depth_cap + 1);
+    uint32_t* stk = lds + (threadIdx.x >> 6) * (depth_cap + 1);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
-    const int64_t src = valid ? (perm ? (int64_t)perm[i] : i) : 0;
-    V3 p = {0.f, 0.f, 0.f};
-    if (valid) p = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
+    // lanes past the end of the batch repeat its last query (and write nothing): they then ask
+    // for no subtree a real lane does not
+    const int64_t ic = valid ? i : n - 1;
+    const int64_t src = perm ? (int64_t)perm[ic] : ic;
+    const V3 p = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
     float sign = 0.f;
     if (ROBUST && KIND != Q_NN && valid) sign = raycast(M, p, nullptr);  // sdf.cpp:110
-    const PacketBest pb = kd_nearest_packet(M, valid, p.x, p.y, p.z, stk);
+    const PacketBest pb = kd_nearest_packet(M, p.x, p.y, p.z, stk);
     // pb.h is nanoflann's answer iff nanoflann does not prune it before visiting it:
     //  (1) no other vertex within b * c (c - 1 ~ 4.5e-6): impossible, see k_query_packet header;
     //  (2) otherwise measure it: every bound tested on the way to pb.h is <= the distance of
@@ -1156,11 +1180,11 @@ struct sdfhip_ctx {
     // device
     float* d_verts = nullptr;
     uint32_t* d_faces = nullptr;
-    uint4* d_kd_nodes = nullptr;
+    float4* d_kd_pn = nullptr;
+    uint32_t* d_kd_split = nullptr;
     float* d_kd_pts = nullptr;
     int32_t* d_kd_vind = nullptr;
-    size_t kd_nodes_cap = 0;
-    float* d_kd_boxes = nullptr;
+    size_t kd_nodes_cap = 0, kd_pos_cap = 0;
     float4* d_kd_pts4 = nullptr;
     float amb_c = 1.f, amb_c2 = 1.f;
     uint32_t* d_fb_list = nullptr;
@@ -1322,8 +1346,8 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     if (h->kd.nodes.size() >= (size_t)KD_MARK)
         return fail(SDFHIP_E_INVALID, "kd-tree too large");
     if (h->kd.nodes.size() > h->kd_nodes_cap) {
-        if (int rc = dalloc(&h->d_kd_nodes, h->kd.nodes.size())) return rc;
-        if (int rc = dalloc(&h->d_kd_boxes, 16 * h->kd.nodes.size())) return rc;
+        if (int rc = dalloc(&h->d_kd_pn, 4 * h->kd.nodes.size())) return rc;
+        if (int rc = dalloc(&h->d_kd_split, h->kd.nodes.size())) return rc;
         h->kd_nodes_cap = h->kd.nodes.size();
     }
     {   // ambiguity factor of the packet pass: c = (1 + w_th + 4u) rounded up, w_th = u(3.02 D + 11.2)
@@ -1336,30 +1360,38 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
         if ((double)c2 < (double)c * (double)c * (1.0 + 4.0 * u)) c2 = std::nextafter(c2, 2.0f);
         h->amb_c2 = c2;
     }
-    // points in tree order
-    std::vector<float> perm_pts(3 * (size_t)h->nv);
-    std::vector<float> perm_pts4(4 * ((size_t)h->nv + 4), 0.f);
-    for (uint32_t i = 0; i < h->nv; ++i) {
-        const float* src = h->h_verts + 3 * (size_t)h->kd.vind[i];
-        perm_pts[3 * (size_t)i] = src[0], perm_pts[3 * (size_t)i + 1] = src[1];
-        perm_pts[3 * (size_t)i + 2] = src[2];
-        perm_pts4[4 * (size_t)i] = src[0], perm_pts4[4 * (size_t)i + 1] = src[1];
-        perm_pts4[4 * (size_t)i + 2] = src[2];
+    // vertices in (padded) tree order; sentinel slots are far away: their distance is +inf
+    const size_t npos = h->kd.pos_vert.size();
+    const size_t nalloc = npos + 16;  // a leaf is always read as ten slots
+    if (nalloc > h->kd_pos_cap) {
+        if (int rc = dalloc(&h->d_kd_pts, 3 * nalloc)) return rc;
+        if (int rc = dalloc(&h->d_kd_pts4, nalloc)) return rc;
+        if (int rc = dalloc(&h->d_kd_vind, nalloc)) return rc;
+        h->kd_pos_cap = nalloc;
     }
-    if (h->nv) {
+    std::vector<float> perm_pts(3 * nalloc, 3.0e38f);
+    std::vector<float> perm_pts4(4 * nalloc, 3.0e38f);
+    for (size_t i = 0; i < npos; ++i) {
+        const int32_t vi = h->kd.pos_vert[i];
+        if (vi < 0) continue;
+        const float* src = h->h_verts + 3 * (size_t)vi;
+        perm_pts[3 * i] = src[0], perm_pts[3 * i + 1] = src[1], perm_pts[3 * i + 2] = src[2];
+        perm_pts4[4 * i] = src[0], perm_pts4[4 * i + 1] = src[1], perm_pts4[4 * i + 2] = src[2];
+    }
+    if (h->nv)
         HIPC(hipMemcpyAsync(h->d_verts, h->h_verts, sizeof(float) * 3 * (size_t)h->nv,
                             hipMemcpyHostToDevice, s));
-        HIPC(hipMemcpyAsync(h->d_kd_pts, perm_pts.data(), sizeof(float) * 3 * (size_t)h->nv,
+    HIPC(hipMemcpyAsync(h->d_kd_pts, perm_pts.data(), sizeof(float) * perm_pts.size(),
+                        hipMemcpyHostToDevice, s));
+    if (npos)
+        HIPC(hipMemcpyAsync(h->d_kd_vind, h->kd.pos_vert.data(), sizeof(int32_t) * npos,
                             hipMemcpyHostToDevice, s));
-        HIPC(hipMemcpyAsync(h->d_kd_vind, h->kd.vind.data(), sizeof(int32_t) * (size_t)h->nv,
-                            hipMemcpyHostToDevice, s));
-    }
     HIPC(hipMemcpyAsync(h->d_kd_pts4, perm_pts4.data(), sizeof(float) * perm_pts4.size(),
                         hipMemcpyHostToDevice, s));
     if (!h->kd.nodes.empty()) {
-        HIPC(hipMemcpyAsync(h->d_kd_nodes, h->kd.nodes.data(), sizeof(uint4) * h->kd.nodes.size(),
+        HIPC(hipMemcpyAsync(h->d_kd_pn, h->kd.nodes.data(), sizeof(sdfk::KdNodeH) * h->kd.nodes.size(),
                             hipMemcpyHostToDevice, s));
-        HIPC(hipMemcpyAsync(h->d_kd_boxes, h->kd.boxes.data(), sizeof(float) * 16 * h->kd.boxes.size(),
+        HIPC(hipMemcpyAsync(h->d_kd_split, h->kd.split.data(), sizeof(uint32_t) * h->kd.split.size(),
                             hipMemcpyHostToDevice, s));
     }
     HIPC(hipStreamSynchronize(s));  // perm_pts is pageable and about to go out of scope
@@ -1373,12 +1405,12 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
 
 MeshDev mesh_view(const sdfhip_ctx* h) {
     MeshDev M;
-    M.kd_nodes = h->d_kd_nodes;
+    M.kd_pn = h->d_kd_pn;
+    M.kd_split = h->d_kd_split;
     M.kd_pts = h->d_kd_pts;
     M.kd_vind = h->d_kd_vind;
     M.kd_root = h->kd.root_ref;
     for (int d = 0; d < 6; ++d) M.bb[d] = h->aabb[d];
-    M.kd_boxes = h->d_kd_boxes;
     M.kd_pts4 = h->d_kd_pts4;
     M.amb_c = h->amb_c;
     M.amb_c2 = h->amb_c2;
@@ -1480,12 +1512,10 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     const bool needs_kd = !(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST));
     const uint32_t depth = (uint32_t)(h->kd.depth > 0 ? h->kd.depth : 1);
     const bool sort_any = h->opt_sort && n >= h->opt_sort_min;
-    const bool packet_any = sort_any && needs_kd && h->opt_packet && depth < 64;  // nearbits: 64 levels
+    const bool packet_any = sort_any && needs_kd && h->opt_packet && depth < 4096;
     const int64_t fb_cap = packet_any ? (n < (1ll << 27) ? n : (1ll << 27)) : 0;
     if (sort_any)
         if (int rc = reserve_query_ws(h, n < chunk ? n : chunk, fb_cap)) return rc;
-    ProfScope prof{h, s};
-    if (int rc = prof.begin()) return rc;
     int64_t deferred_pts = 0;  // points whose near ties may sit in the deferred list
     int flip = 0;              // d_fb_count[flip] holds the current list length
     if (packet_any) HIPC(hipMemsetAsync(h->d_fb_count, 0, 2 * sizeof(uint32_t), s));
@@ -1519,10 +1549,13 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         if (perm && packet_any) {
             if (deferred_pts + m > h->fb_cap)
                 if (int rc = flush()) return rc;
-            const size_t lds = (size_t)(PBLOCK / 64) * 2 * (depth + 1) * sizeof(uint32_t);
+            const size_t lds = (size_t)(PBLOCK / 64) * (depth + 1) * sizeof(uint32_t);
             constexpr int PK = KIND == Q_DETAIL ? Q_NN : KIND;
+            ProfScope prof{h, s};  // the dominant kernel, one event pair per launch
+            if (int rc = prof.begin()) return rc;
             k_query_packet<PK, ROBUST><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, lds, s>>>(
                 M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, depth);
+            if (int rc = prof.end(m)) return rc;
             exclusive_scan_u32(h->d_amb_cnt, (uint32_t)((m + 63) / 64), h->d_amb_s1, h->d_amb_s2, s);
             k_fb_compact<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(
                 h->d_amb_mask, h->d_amb_cnt, perm, m, (uint32_t)off, h->d_fb_list, h->d_fb_count + flip,
@@ -1531,11 +1564,13 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             flip ^= 1;
             deferred_pts += m;
         } else {
+            ProfScope prof{h, s};
+            if (int rc = prof.begin()) return rc;
             if (int rc = launch_strict<KIND, ROBUST>(h, M, p, perm, m, trunc, o, nullptr, s)) return rc;
+            if (int rc = prof.end(m)) return rc;
         }
     }
-    if (int rc = flush()) return rc;
-    return prof.end(n);
+    return flush();
 }
 
 int run_query(sdfhip_ctx* h, int kind, const float* d_pts, int64_t n, int trunc, void* d_out,
@@ -1690,9 +1725,6 @@ int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32
         rc = fail(SDFHIP_E_HIP, "hipStreamCreate failed");
     A(dalloc(&h->d_verts, 3 * (size_t)nv));
     A(dalloc(&h->d_faces, 3 * (size_t)nf));
-    A(dalloc(&h->d_kd_pts, 3 * (size_t)nv));
-    A(dalloc(&h->d_kd_vind, (size_t)nv));
-    A(dalloc(&h->d_kd_pts4, (size_t)nv + 4));
     A(dalloc(&h->d_fb_count, 2));
     A(dalloc(&h->d_adj_off, (size_t)nv + 1));
     A(dalloc(&h->d_adj_faces, 3 * (size_t)nf));
@@ -1737,11 +1769,11 @@ void sdfhip_destroy(sdfhip_t* h) {
     if (!h) return;
     DevGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_nodes, h->d_kd_pts, h->d_kd_vind, h->d_adj_off,
+    void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_pts, h->d_kd_vind, h->d_adj_off,
                     h->d_adj_faces, h->d_geo, h->d_rface, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
-                    h->topo.depthI, h->d_qkeys, h->d_qperm, h->d_qbounds, h->d_gstack, h->d_kd_boxes, h->d_kd_pts4,
+                    h->topo.depthI, h->d_qkeys, h->d_qperm, h->d_qbounds, h->d_gstack, h->d_kd_pts4,
                     h->d_fb_list, h->d_fb_count, h->d_amb_mask, h->d_amb_cnt, h->d_amb_s1, h->d_amb_s2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
