@@ -482,7 +482,10 @@ __global__ __launch_bounds__(QBLOCK) void k_query(MeshDev M, const float* __rest
 // the query is "ambiguous" and is appended to a fallback list that the strict per-lane
 // kernel (kd_nearest: exact emulation) processes afterwards.  Parity is by construction.
 // =========================================================================================
-constexpr int PBLOCK = 256;
+#ifndef SDFK_PBLOCK
+#define SDFK_PBLOCK 64
+#endif
+constexpr int PBLOCK = SDFK_PBLOCK;
 
 
 // result of the packet pass for one lane
@@ -783,10 +786,11 @@ __global__ void k_face_precompute(const float* __restrict__ verts, const uint32_
 //                 among equal digits; chunk bases are scanned in LDS per digit
 // =========================================================================================
 constexpr int RS_THREADS = 256;
-constexpr int RS_ITEMS = 8;
-constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 2048
-constexpr int RS_CHUNKS = RS_TILE / 64;         // 32
+constexpr int RS_ITEMS = 12;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 3072
+constexpr int RS_CHUNKS = RS_TILE / 64;         // 48
 
+// element (k, t) of a tile = index base + k * 256 + t, so a wave reads 64 consecutive keys
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t* __restrict__ keys, uint32_t n,
                                                         int shift, uint32_t* __restrict__ hist,
                                                         uint32_t ntiles) {
@@ -851,51 +855,83 @@ static int exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* s1, uint32_t
     return 0;
 }
 
+// Stable scatter of one tile.  Ranks come from per-64-key-chunk ballot "match" masks; the tile
+// is first permuted into digit order inside LDS so that consecutive lanes then write
+// consecutive global addresses (runs of tile/256 elements per digit instead of single keys).
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift,
     const uint32_t* __restrict__ hist, uint32_t ntiles, int vals_iota) {
-    __shared__ uint32_t cnt[RS_CHUNKS * 256];  // 32 KB
+    __shared__ uint16_t cnt[RS_CHUNKS * 256];  // per (chunk, digit) counts -> offsets   24 KB
+    __shared__ uint32_t skey[RS_TILE];         // tile in digit order                   12 KB
+    __shared__ uint32_t sval[RS_TILE];         //                                       12 KB
+    __shared__ uint32_t bstart[256];           // first local slot of each digit
+    __shared__ uint32_t gbase[256];            // global base of each digit for this tile
+    __shared__ uint32_t wsum[4];
     for (int k = threadIdx.x; k < RS_CHUNKS * 256; k += RS_THREADS) cnt[k] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t base = blockIdx.x * RS_TILE;
-    uint32_t key[RS_ITEMS], rank[RS_ITEMS];
+    uint32_t key[RS_ITEMS], val[RS_ITEMS];
+    uint16_t rank[RS_ITEMS];
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    // wave w owns chunks w*8 .. w*8+7 (keys [chunk*64, chunk*64+64) of the tile)
     for (int k = 0; k < RS_ITEMS; ++k) {
-        const int chunk = w * RS_ITEMS + k;
-        const uint32_t i = base + chunk * 64 + lane;
+        const int chunk = k * 4 + w;  // ascending key index
+        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
         const bool valid = i < n;
         key[k] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        val[k] = valid ? (vals_iota ? i : vals_in[i]) : 0u;
         const uint32_t dg = (key[k] >> shift) & 255u;
         unsigned long long m = __ballot(valid);
         for (int b = 0; b < 8; ++b) {
             const unsigned long long bl = __ballot((dg >> b) & 1u);
             m &= ((dg >> b) & 1u) ? bl : ~bl;
         }
-        rank[k] = __popcll(m & lt);
-        if (valid && rank[k] == 0) cnt[chunk * 256 + dg] = __popcll(m);
+        rank[k] = (uint16_t)__popcll(m & lt);
+        if (valid && rank[k] == 0) cnt[chunk * 256 + dg] = (uint16_t)__popcll(m);
     }
     __syncthreads();
-    {  // per digit: exclusive scan over chunks, seeded with the global base of this tile
+    {   // thread = digit: offsets of its chunks, then a block scan of the digit totals
         const uint32_t dg = threadIdx.x;
-        uint32_t run = hist[dg * ntiles + blockIdx.x];
+        uint32_t run = 0;
         for (int c = 0; c < RS_CHUNKS; ++c) {
             const uint32_t t = cnt[c * 256 + dg];
-            cnt[c * 256 + dg] = run;
+            cnt[c * 256 + dg] = (uint16_t)run;
             run += t;
         }
+        uint32_t x = run;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        bstart[dg] = woff + x - run;
+        gbase[dg] = hist[dg * ntiles + blockIdx.x];
     }
     __syncthreads();
     for (int k = 0; k < RS_ITEMS; ++k) {
-        const int chunk = w * RS_ITEMS + k;
-        const uint32_t i = base + chunk * 64 + lane;
+        const int chunk = k * 4 + w;
+        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
         if (i < n) {
             const uint32_t dg = (key[k] >> shift) & 255u;
-            const uint32_t dst = cnt[chunk * 256 + dg] + rank[k];
-            keys_out[dst] = key[k];
-            vals_out[dst] = vals_iota ? i : vals_in[i];
+            const uint32_t slot = bstart[dg] + cnt[chunk * 256 + dg] + rank[k];
+            skey[slot] = key[k];
+            sval[slot] = val[k];
+        }
+    }
+    __syncthreads();
+    const uint32_t tile_n = (n - base) < (uint32_t)RS_TILE ? (n - base) : (uint32_t)RS_TILE;
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const uint32_t slot = k * RS_THREADS + threadIdx.x;
+        if (slot < tile_n) {
+            const uint32_t kk = skey[slot];
+            const uint32_t dg = (kk >> shift) & 255u;
+            const uint32_t dst = gbase[dg] + (slot - bstart[dg]);
+            keys_out[dst] = kk;
+            vals_out[dst] = sval[slot];
         }
     }
 }
@@ -929,13 +965,16 @@ struct RadixSorter {
         keys_alt = vals_alt = hist = sums1 = sums2 = nullptr;
         cap = 0;
     }
-    // sorts (keys, vals) ascending by the low `bits` bits of keys; the result lands back in
-    // keys/vals (an even number of passes).  iota = 1: input values are taken as 0..n-1.
-    int sort(uint32_t* keys, uint32_t* vals, uint32_t n, int bits, int iota, hipStream_t s) {
+    // sorts (keys, vals) ascending by the low `bits` bits of keys (8 bits per pass).  The result
+    // is in *keys_out / *vals_out: the caller's buffers after an even number of passes, the
+    // sorter's alternates after an odd number.  iota = 1: input values are taken as 0..n-1.
+    int sort(uint32_t* keys, uint32_t* vals, uint32_t n, int bits, int iota, hipStream_t s,
+             uint32_t** keys_out, uint32_t** vals_out) {
+        if (keys_out) *keys_out = keys;
+        if (vals_out) *vals_out = vals;
         if (n == 0) return 0;
         if (int rc = reserve(n)) return rc;
-        int passes = (bits + 7) / 8;
-        if (passes & 1) ++passes;
+        const int passes = (bits + 7) / 8;
         const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
         const uint32_t nh = 256u * ntiles;
         const uint32_t n1 = (nh + 2047) / 2048, n2 = (n1 + 2047) / 2048;
@@ -952,6 +991,8 @@ struct RadixSorter {
             t = vi;
             vi = vo, vo = t;
         }
+        if (keys_out) *keys_out = ki;
+        if (vals_out) *vals_out = vi;
         HIPC(hipGetLastError());
         return 0;
     }
@@ -1002,16 +1043,35 @@ __global__ void k_bounds_init(uint32_t* b) {
     if (threadIdx.x < 3) b[threadIdx.x] = 0xFFFFFFFFu;
     else if (threadIdx.x < 6) b[threadIdx.x] = 0u;
 }
+// flat float view of the [n,3] points: thread-contiguous float4 loads (coordinate = index % 3);
+// base pointers from hipMalloc / torch are 16-byte aligned, the tail is read scalar
 __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, int64_t n, uint32_t* b) {
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        for (int d = 0; d < 3; ++d) {
-            const float v = pts[3 * i + d];
-            if (v == v && fabsf(v) <= FLT_MAX) {
-                lo[d] = fminf(lo[d], v);
-                hi[d] = fmaxf(hi[d], v);
+    const int64_t nf = 3 * n;
+    const bool aligned = (((uintptr_t)pts) & 15) == 0;
+    const int64_t ngroups = aligned ? nf / 12 : 0;  // 12 floats = 4 points = 3 float4
+    const float4* p4 = (const float4*)pts;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = p4[3 * g], c = p4[3 * g + 1], d = p4[3 * g + 2];
+        const float v[12] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const float x = v[k];
+            if (fabsf(x) <= FLT_MAX) {  // skips NaN and inf
+                lo[k % 3] = fminf(lo[k % 3], x);
+                hi[k % 3] = fmaxf(hi[k % 3], x);
             }
+        }
+    }
+    for (int64_t i = 12 * ngroups + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = pts[i];
+        const int d = (int)(i % 3);
+        if (fabsf(x) <= FLT_MAX) {
+            if (d == 0) lo[0] = fminf(lo[0], x), hi[0] = fmaxf(hi[0], x);
+            else if (d == 1) lo[1] = fminf(lo[1], x), hi[1] = fmaxf(hi[1], x);
+            else lo[2] = fminf(lo[2], x), hi[2] = fmaxf(hi[2], x);
         }
     }
     for (int d = 0; d < 3; ++d) {
@@ -1037,7 +1097,8 @@ __global__ void k_query_morton(const float* __restrict__ pts, uint32_t n, const 
         const float ext = ord2f(b[3 + d]) - lo[d];
         inv[d] = ext > 0.f ? 1024.f / ext : 0.f;
     }
-    keys[i] = morton30(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], lo, inv);
+    // 8 bits per axis are plenty for wave coherence: 3 radix passes instead of 4
+    keys[i] = morton30(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], lo, inv) >> 6;
 }
 
 // =========================================================================================
@@ -1222,7 +1283,7 @@ struct sdfhip_ctx {
     void* d_stage_out = nullptr;
     int64_t q_cap = 0;
     // options
-    int64_t opt_sort = 1, opt_sort_min = 8192, opt_chunk = 1 << 24;
+    int64_t opt_sort = 1, opt_sort_min = 8192, opt_chunk = 1 << 27;
     hipStream_t stream = nullptr;  // internal stream for create/update and host entry points
     std::mutex mu;
     std::mt19937 rng;
@@ -1291,7 +1352,7 @@ int build_topology(sdfhip_ctx* h) {
         B.inv[d] = ext > 0.f ? 1024.f / ext : 0.f;
     }
     k_face_morton<<<(n + 255) / 256, 256, 0, s>>>(h->d_geo, n, B, h->d_codes);
-    if (int rc = h->sorter.sort(h->d_codes, h->d_sorted_face, n, 30, 1, s)) return rc;
+    if (int rc = h->sorter.sort(h->d_codes, h->d_sorted_face, n, 32, 1, s, nullptr, nullptr)) return rc;
     HIPC(hipMemsetAsync(h->d_maxdepth, 0, sizeof(uint32_t), s));
     if (n > 1) k_lbvh_karras<<<(n - 1 + 255) / 256, 256, 0, s>>>(h->d_codes, (int)n, h->topo);
     k_lbvh_layout<<<(2 * n - 1 + 255) / 256, 256, 0, s>>>((int)n, h->topo, h->d_sorted_face,
@@ -1539,12 +1600,14 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         const uint32_t* perm = nullptr;
         if (h->opt_sort && m >= h->opt_sort_min) {
             k_bounds_init<<<1, 64, 0, s>>>(h->d_qbounds);
-            const int nb = (int)((m + 255) / 256 < 2048 ? (m + 255) / 256 : 2048);
+            const int nb = (int)((m / 4 + 255) / 256 < 4096 ? (m / 4 + 255) / 256 + 1 : 4096);
             k_bounds<<<nb, 256, 0, s>>>(p, m, h->d_qbounds);
             k_query_morton<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(p, (uint32_t)m, h->d_qbounds,
                                                                        h->d_qkeys);
-            if (int rc = h->sorter.sort(h->d_qkeys, h->d_qperm, (uint32_t)m, 30, 1, s)) return rc;
-            perm = h->d_qperm;
+            uint32_t* sorted_perm = nullptr;
+            if (int rc = h->sorter.sort(h->d_qkeys, h->d_qperm, (uint32_t)m, 24, 1, s, nullptr, &sorted_perm))
+                return rc;
+            perm = sorted_perm;
         }
         if (perm && packet_any) {
             if (deferred_pts + m > h->fb_cap)
