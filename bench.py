@@ -92,26 +92,16 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    # ---- mesh: built on rank 0, replicated by RCCL broadcast --------------------------------
+    # ---- mesh: built on rank 0, replicated by RCCL broadcast (sdf_amd/distributed.py) -------
     res = a.mesh_res
     nv, nf = res * res, 2 * res * res
+    v = f = R = None
     if rank == 0:
         v, f = meshes.torus(res, res)
         R = meshes.random_rotation(1234)
-        tv = torch.from_numpy(v).to(dev)
-        tf = torch.from_numpy(f.astype(np.int32)).to(dev)
-        tR = torch.from_numpy(R).to(dev)
-    else:
-        tv = torch.empty((nv, 3), dtype=torch.float32, device=dev)
-        tf = torch.empty((nf, 3), dtype=torch.int32, device=dev)
-        tR = torch.empty((3, 3), dtype=torch.float32, device=dev)
     if dist is not None:
-        dist.broadcast(tv, 0)
-        dist.broadcast(tf, 0)
-        dist.broadcast(tR, 0)
-    v = tv.cpu().numpy()
-    f = tf.cpu().numpy().astype(np.uint32)
-    R = tR.cpu().numpy()
+        from sdf_amd.distributed import broadcast_mesh
+        v, f, R = broadcast_mesh(v, f, R, src=0, device=dev)
     s = sdf_amd.SDF(v, f, robust=True, copy=True, device=local)
     s.set_raycast_axes(R)
     if a.no_sort:

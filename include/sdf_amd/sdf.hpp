@@ -1,0 +1,196 @@
+// sdf_amd/sdf.hpp — C++ façade with the reference's `sdf::SDF` surface
+// (include/sdf/sdf.hpp:150-258 of sxyu/sdf) over the C ABI of sdfhip.h.
+//
+// Two spellings of every method:
+//   * plain-pointer / std::vector signatures: always available;
+//   * the reference's Eigen signatures (Eigen::Ref<const Points> ...), compiled only when
+//     <Eigen/Core> is on the include path.  Eigen is absent from the build image, so that
+//     half is not compile-tested there; it is a thin wrapper over the pointer half.
+//
+// Constructor, update() and query signatures, defaults (`robust = true`, `copy = false`),
+// the public const members `robust` / `own_data`, and the stderr messages of the mutable
+// accessors follow the reference.  `n_threads` is accepted and ignored (GPU path).
+// Errors that the reference leaves undefined (empty mesh, no device, ...) throw
+// std::runtime_error with the C ABI's message.
+//
+// Header-only: link with -lsdfhip (sdf_amd/libsdfhip.so).
+#pragma once
+#ifndef SDF_AMD_SDF_HPP_
+#define SDF_AMD_SDF_HPP_
+
+#include <cstdint>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../sdfhip.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#define SDF_AMD_HAVE_EIGEN 1
+#endif
+#endif
+
+namespace sdf {
+
+using Index = uint32_t;  // sdf.hpp:43
+
+#ifdef SDF_AMD_HAVE_EIGEN
+using Points = Eigen::Matrix<float, Eigen::Dynamic, 3, Eigen::RowMajor>;       // sdf.hpp:44
+using Triangles = Eigen::Matrix<Index, Eigen::Dynamic, 3, Eigen::RowMajor>;    // sdf.hpp:46
+using Vector = Eigen::Matrix<float, Eigen::Dynamic, 1>;                         // sdf.hpp:49
+#endif
+
+struct SDF {
+    // ---- plain-pointer construction: verts [n_verts,3] float32, faces [n_faces,3] uint32 ----
+    SDF(const float* verts, uint32_t n_verts, const Index* faces, uint32_t n_faces, bool robust = true,
+        bool copy = false, int device = -1)
+        : robust(robust), own_data(copy) {
+        check(sdfhip_create(verts, n_verts, faces, n_faces, robust ? 1 : 0, copy ? 1 : 0, device, &h_));
+    }
+#ifdef SDF_AMD_HAVE_EIGEN
+    // sdf.hpp:168-169.  copy = false keeps referencing the caller's matrices (sdf.cpp:339).
+    SDF(Eigen::Ref<const Points> verts, Eigen::Ref<const Triangles> faces, bool robust = true,
+        bool copy = false)
+        : SDF(verts.data(), (uint32_t)verts.rows(), faces.data(), (uint32_t)faces.rows(), robust, copy) {}
+#endif
+    ~SDF() { sdfhip_destroy(h_); }
+    SDF(const SDF&) = delete;  // as the reference: const members + pImpl
+    SDF& operator=(const SDF&) = delete;
+
+    /*** PRIMARY INTERFACE (sdf.hpp:172-208) ***/
+    std::vector<float> operator()(const float* points, int64_t n, bool trunc_aabb = false,
+                                  int /*n_threads*/ = 0) const {
+        std::vector<float> out((size_t)n);
+        check(sdfhip_sdf(h_, points, n, trunc_aabb ? 1 : 0, out.data()));
+        return out;
+    }
+    std::vector<int> nn(const float* points, int64_t n, int /*n_threads*/ = 0) const {
+        std::vector<int> out((size_t)n);
+        check(sdfhip_nn(h_, points, n, out.data()));
+        return out;
+    }
+    std::vector<uint8_t> contains(const float* points, int64_t n, int /*n_threads*/ = 0) const {
+        std::vector<uint8_t> out((size_t)n);
+        check(sdfhip_contains(h_, points, n, out.data()));
+        return out;
+    }
+    // device-resident points / results on `stream` (hipStream_t), asynchronous
+    void sdf_device(const float* d_points, int64_t n, bool trunc_aabb, float* d_out, void* stream) const {
+        check(sdfhip_sdf_device(h_, d_points, n, trunc_aabb ? 1 : 0, d_out, stream));
+    }
+    void contains_device(const float* d_points, int64_t n, uint8_t* d_out, void* stream) const {
+        check(sdfhip_contains_device(h_, d_points, n, d_out, stream));
+    }
+    void nn_device(const float* d_points, int64_t n, int32_t* d_out, void* stream) const {
+        check(sdfhip_nn_device(h_, d_points, n, d_out, stream));
+    }
+#ifdef SDF_AMD_HAVE_EIGEN
+    Vector operator()(Eigen::Ref<const Points> points, bool trunc_aabb = false,
+                      int /*n_threads*/ = std::thread::hardware_concurrency()) const {
+        Vector out(points.rows());
+        check(sdfhip_sdf(h_, points.data(), points.rows(), trunc_aabb ? 1 : 0, out.data()));
+        return out;
+    }
+    Eigen::VectorXi nn(Eigen::Ref<const Points> points,
+                       int /*n_threads*/ = std::thread::hardware_concurrency()) const {
+        Eigen::VectorXi out(points.rows());
+        check(sdfhip_nn(h_, points.data(), points.rows(), out.data()));
+        return out;
+    }
+    Eigen::Matrix<bool, Eigen::Dynamic, 1> contains(
+        Eigen::Ref<const Points> points, int /*n_threads*/ = std::thread::hardware_concurrency()) const {
+        Eigen::Matrix<bool, Eigen::Dynamic, 1> out(points.rows());
+        static_assert(sizeof(bool) == 1, "bool must be one byte");
+        check(sdfhip_contains(h_, points.data(), points.rows(), reinterpret_cast<uint8_t*>(out.data())));
+        return out;
+    }
+#endif
+    // sdf.hpp:206-208 / sdf.cpp:391
+    void update() { check(sdfhip_update(h_)); }
+
+    // the reference's rotation is private and random (sdf.cpp:43-48); parity needs it injectable
+    void set_raycast_axes(const float R[9], bool pin = true) { check(sdfhip_set_raycast_axes(h_, R, pin)); }
+    void get_raycast_axes(float R[9]) const { check(sdfhip_get_raycast_axes(h_, R)); }
+
+    /*** DATA ACCESSORS (sdf.hpp:215-245) ***/
+    std::vector<int> adj_faces(int pointid) const {
+        const int32_t* ids = nullptr;
+        const int n = sdfhip_adj_faces(h_, (uint32_t)pointid, &ids);
+        if (n < 0) check(n);
+        return std::vector<int>(ids, ids + n);
+    }
+    float surface_area() const {
+        float a = 0.f;
+        check(sdfhip_surface_area(h_, &a));
+        return a;
+    }
+    std::vector<float> face_areas_vec() const {
+        std::vector<float> out(sdfhip_num_faces(h_));
+        check(sdfhip_face_areas(h_, out.data()));
+        return out;
+    }
+    std::vector<float> face_normals_vec() const {
+        std::vector<float> out(3 * (size_t)sdfhip_num_faces(h_));
+        check(sdfhip_face_normals(h_, out.data()));
+        return out;
+    }
+    void aabb(float out[6]) const { check(sdfhip_aabb(h_, out)); }
+    uint32_t num_verts() const { return sdfhip_num_verts(h_); }
+    uint32_t num_faces() const { return sdfhip_num_faces(h_); }
+    const float* verts_data() const { return sdfhip_verts(h_); }
+    const Index* faces_data() const { return sdfhip_faces(h_); }
+    float* verts_mutable_data() {  // sdf.cpp:369-375
+        if (!own_data) std::cerr << "ERROR: 'verts' is non mutable, construct with copy=True\n";
+        return sdfhip_verts_mutable(h_);
+    }
+    Index* faces_mutable_data() {  // sdf.cpp:360-366
+        if (!own_data) std::cerr << "ERROR: 'faces' is non mutable, construct with copy=True\n";
+        return sdfhip_faces_mutable(h_);
+    }
+#ifdef SDF_AMD_HAVE_EIGEN
+    Vector face_areas() const {
+        Vector out(num_faces());
+        check(sdfhip_face_areas(h_, out.data()));
+        return out;
+    }
+    Points face_normals() const {
+        Points out(num_faces(), 3);
+        check(sdfhip_face_normals(h_, out.data()));
+        return out;
+    }
+    Eigen::Matrix<float, 6, 1> aabb() const {
+        Eigen::Matrix<float, 6, 1> out;
+        check(sdfhip_aabb(h_, out.data()));
+        return out;
+    }
+    Eigen::Map<const Triangles> faces() const { return {faces_data(), (Eigen::Index)num_faces(), 3}; }
+    Eigen::Map<const Points> verts() const { return {verts_data(), (Eigen::Index)num_verts(), 3}; }
+    Eigen::Map<Points> verts_mutable() {
+        float* p = verts_mutable_data();
+        return {p, p ? (Eigen::Index)num_verts() : 0, 3};
+    }
+    Eigen::Map<Triangles> faces_mutable() {
+        Index* p = faces_mutable_data();
+        return {p, p ? (Eigen::Index)num_faces() : 0, 3};
+    }
+#endif
+
+    const bool robust;    // sdf.hpp:242
+    const bool own_data;  // sdf.hpp:245
+
+    sdfhip_t* handle() const { return h_; }
+
+   private:
+    static void check(int rc) {
+        if (rc != 0) throw std::runtime_error(std::string("sdfhip: ") + sdfhip_last_error());
+    }
+    sdfhip_t* h_ = nullptr;
+};
+
+}  // namespace sdf
+
+#endif  // SDF_AMD_SDF_HPP_

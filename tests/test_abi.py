@@ -72,3 +72,20 @@ def test_python_surface_matches_pysdf():
                  "robust", "own_data", "__repr__"):
         assert hasattr(S, name)
     assert sdf_amd.num_threads == min(os.cpu_count(), 32)
+
+
+def test_cpp_facade_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """include/sdf_amd/sdf.hpp mirrors sdf::SDF (sdf.hpp:150-258); tests/cpp/facade_smoke.cpp uses it."""
+    import subprocess
+    import torch
+    exe = str(tmp_path / "facade_smoke")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "facade_smoke.cpp"),
+                           "-L" + os.path.join(ROOT, "sdf_amd"), "-lsdfhip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "sdf_amd"), "-Wl,-rpath,/opt/rocm/lib",
+                           "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3 and "no HIP device" in r.stdout

@@ -231,3 +231,17 @@ def test_large_mesh_properties_full_size():
     assert (n[:k] == o.nn(pts[:k])).all()
     assert (c[:k] == o.contains(pts[:k])).all()
     assert same_float(d[:k], o(pts[:k])).all()
+
+
+def test_cpp_facade_runs_on_gpu(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "facade_smoke")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "facade_smoke.cpp"),
+                           "-L" + os.path.join(root, "sdf_amd"), "-lsdfhip",
+                           "-Wl,-rpath," + os.path.join(root, "sdf_amd"), "-Wl,-rpath,/opt/rocm/lib",
+                           "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
