@@ -160,6 +160,17 @@ def main():
                 "kernel": "k_query_packet<Q_SDF,robust>", "kernel_ms_avg": k_ms,
                 "points_per_launch": pts_per_launch, "launches": kl,
                 "kernel_share_of_step": st["query_kernel_ms"] / (dt * 1e3)}
+    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes of this same
+    # command, tools/collect_profiles.sh -> profiles/*_pmc.json); cannot be read live
+    try:
+        import glob
+        pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+        pm = json.load(open(pj))
+        if pm.get("traffic_bytes_per_launch") and n == 125_000_000 and not a.no_sort:
+            roofline["traffic"] = pm["traffic_bytes_per_launch"]
+            roofline["traffic_source"] = os.path.relpath(pj, ROOT)
+    except (IndexError, OSError, ValueError):
+        pass
     extra = {}
     if not a.no_grid:
         # the metric's second figure: ms for a 256^3 grid (16,777,216 points) on the same mesh
