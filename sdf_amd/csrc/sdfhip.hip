@@ -1675,7 +1675,7 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
     DevGuard g(h->device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
     const size_t osz = kind == Q_CONTAINS ? 1 : (kind == Q_DETAIL ? 12 : 4);
-    const int64_t chunk = 1 << 22;
+    const int64_t chunk = 1 << 26;  // device staging batch: large batches keep the Morton-sorted waves compact
     const int64_t cap = n < chunk ? n : chunk;
     float* d_p = nullptr;
     void* d_o = nullptr;
