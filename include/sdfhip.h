@@ -139,7 +139,8 @@ typedef struct {
 int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* out);
 
 /* Tuning knobs (no counterpart). key: "sort_queries" (0/1, default 1: Morton-sort query
- * chunks of >= sort_min points), "sort_min", "chunk" (points per internal chunk), "profile" (1: time every query kernel launch
+ * chunks of >= sort_min points), "sort_min", "chunk" (points per internal chunk), "packet" (0: strict kernel only),
+ * "build_threads" (host threads of the kd-tree build; default min(cores, OMP_NUM_THREADS, 16)), "profile" (1: time every query kernel launch
  * with hipEvents on its stream, read back through sdfhip_get_stats; 2: same and reset). */
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t value);
 

@@ -9,19 +9,27 @@
 // GPU:
 //
 //   * points are stored in permuted ("vind") order, so a leaf is a contiguous run and
-//     the traversal needs no index indirection; `vind` maps the winner back once.
+//     the traversal needs no index indirection; `pos_vert` maps the winner back once.
 //     Tree positions are PADDED: leaf j owns positions [10 j, 10 j + 10), of which the first
 //     `count` hold its vertices in nanoflann's order and the rest a far-away sentinel
-//     (vind = -1), so that a whole leaf can be evaluated as ten straight-line slots.
+//     (pos_vert = -1), so that a whole leaf can be evaluated as ten straight-line slots.
 //   * only internal nodes are materialised, 64 B each (one s_load_dwordx16 / four dwordx4):
 //         { box1.lo[3], box1.hi[3], box2.lo[3], box2.hi[3],      tight boxes of the children
 //           divlow, divhigh, ref1 | feat<<29, ref2 }
 //     a child reference is either an internal node index or, with bit 31 set, a leaf
-//     packed as  left<<4 | count  (count <= 10, left < 2^25).  `split[i]` = first tree-order
+//     packed as  pos<<4 | count  (count <= 10, pos < 2^25).  `split[i]` = first tree
 //     position of child 2's vertices (child 1 holds the positions below it).
 //   * nodes are emitted in DFS pre-order, near the order queries walk them.
+//
+// The recursion is task-parallel: after a node's own split its two ranges are independent, so
+// the top levels hand one child to another thread; sub-ranges are built into local arrays and
+// spliced into the global pre-order numbering afterwards.  The result is identical to the
+// serial build (it has to be: the numbering is part of the tie rule's data).
 #pragma once
 #include <cstdint>
+#include <future>
+#include <memory>
+#include <thread>
 #include <vector>
 
 namespace sdfk {
@@ -39,11 +47,11 @@ static_assert(sizeof(KdNodeH) == 64, "device layout");
 constexpr uint32_t KD_LEAF_BIT = 0x80000000u;
 constexpr uint32_t KD_FEAT_SHIFT = 29;
 constexpr uint32_t KD_REF_MASK = 0x1FFFFFFFu;  // strips leaf bit and feat bits
-constexpr uint32_t KD_MAX_POINTS = 1u << 23;  // padded positions (<= 10 per vertex) fit 25 bits
+constexpr uint32_t KD_MAX_POINTS = 1u << 23;   // padded positions (<= 10 per vertex) fit 25 bits
 
 struct KdHost {
-    std::vector<int32_t> vind;     // nanoflann's permutation (dense, size n)
-    std::vector<int32_t> pos_vert; // padded tree position -> vertex index, -1 = sentinel slot
+    std::vector<int32_t> vind;      // nanoflann's permutation (dense, size n)
+    std::vector<int32_t> pos_vert;  // padded tree position -> vertex index, -1 = sentinel slot
     uint32_t n_leaves = 0;
     std::vector<KdNodeH> nodes;
     std::vector<uint32_t> split;  // parallel to nodes
@@ -51,37 +59,49 @@ struct KdHost {
     int depth = 0;                    // max internal nodes on a root-to-leaf path
     float bbox[6] = {0, 0, 0, 0, 0, 0};  // min xyz, max xyz (= mesh AABB, sdf.cpp:36-37)
 
-    void build(const float* pts, uint32_t n);
+    // threads <= 1: serial.  Otherwise up to ~2*threads ranges are built concurrently.
+    void build(const float* pts, uint32_t n, int threads = 0);
 
    private:
     struct Box {
         float lo[3], hi[3];
     };
+    // a built sub-range with LOCAL numbering (node 0 / leaf 0 = its own first)
+    struct Sub {
+        std::vector<KdNodeH> nodes;
+        std::vector<uint32_t> split;
+        std::vector<int32_t> pos_vert;
+        uint32_t n_leaves = 0;
+        uint32_t root = KD_LEAF_BIT;
+        int depth = 0;
+        // task-parallel inner node: nodes.size() == 1 (refs still to be set), children below
+        std::unique_ptr<Sub> c1, c2;
+        uint32_t total_nodes = 0, total_leaves = 0;
+    };
+    struct Cut {
+        int feat;
+        int32_t mid;
+    };
     const float* p_ = nullptr;
     float at(int32_t i, int d) const { return p_[3 * (size_t)i + d]; }
-    uint32_t divide(int32_t left, int32_t right, Box& box, int level);
+    Cut choose_and_partition(int32_t* ind, int32_t count, const Box& box, float& cutval) const;
+    uint32_t divide(Sub& out, int32_t left, int32_t right, Box& box, int level);
+    void divide_par(Sub& out, int32_t left, int32_t right, Box& box, int par_levels, int32_t cutoff);
+    void splice(const Sub& s, uint32_t node_off, uint32_t leaf_off);
+    static uint32_t shift_ref(uint32_t ref, uint32_t node_off, uint32_t leaf_off) {
+        const uint32_t feat = ref & (3u << KD_FEAT_SHIFT);
+        if (ref & KD_LEAF_BIT) {
+            const uint32_t cnt = ref & 15u, pos = (ref & KD_REF_MASK) >> 4;
+            return KD_LEAF_BIT | feat | ((pos + 10u * leaf_off) << 4) | cnt;
+        }
+        return feat | ((ref & KD_REF_MASK) + node_off);
+    }
 };
 
-inline uint32_t KdHost::divide(int32_t left, int32_t right, Box& box, int level) {
-    const int32_t count = right - left;
-    int32_t* ind = vind.data() + left;
-    if (count <= 10) {
-        // leaf: tight box of its points (nanoflann.hpp:862-879)
-        for (int d = 0; d < 3; ++d) box.lo[d] = box.hi[d] = at(ind[0], d);
-        for (int32_t k = 1; k < count; ++k)
-            for (int d = 0; d < 3; ++d) {
-                float v = at(ind[k], d);
-                if (box.lo[d] > v) box.lo[d] = v;
-                if (box.hi[d] < v) box.hi[d] = v;
-            }
-        const uint32_t base = 10u * n_leaves++;
-        pos_vert.resize((size_t)base + 10, -1);
-        for (int32_t k = 0; k < count; ++k) pos_vert[base + k] = ind[k];
-        return KD_LEAF_BIT | (base << 4) | (uint32_t)count;
-    }
-    if (level + 1 > depth) depth = level + 1;
-
-    // --- choose the cut (nanoflann.hpp:909-945) ---
+// split choice (nanoflann.hpp:909-945) + the two Hoare passes (967-1003, signed indices, "!hi"
+// guards kept) + the split index rule (950-955)
+inline KdHost::Cut KdHost::choose_and_partition(int32_t* ind, int32_t count, const Box& box,
+                                                float& cutval) const {
     float span[3], max_span = box.hi[0] - box.lo[0];
     for (int d = 0; d < 3; ++d) {
         span[d] = box.hi[d] - box.lo[d];
@@ -108,8 +128,6 @@ inline uint32_t KdHost::divide(int32_t left, int32_t right, Box& box, int level)
         cut = fmn;
     else if (cut > fmx)
         cut = fmx;
-
-    // --- two Hoare passes (nanoflann.hpp:967-1003), signed indices, "!hi" guards kept ---
     int32_t lo = 0, hi = count - 1;
     for (;;) {
         while (lo <= hi && at(ind[lo], feat) < cut) ++lo;
@@ -139,21 +157,45 @@ inline uint32_t KdHost::divide(int32_t left, int32_t right, Box& box, int level)
         mid = lim2;
     else
         mid = count / 2;
+    cutval = cut;
+    return {feat, mid};
+}
 
-    // --- recurse; children return their tight boxes (nanoflann.hpp:889-903) ---
-    const uint32_t self = (uint32_t)nodes.size();
-    nodes.push_back({});
-    split.push_back(0u);
+// serial recursion into `out` (local numbering); returns the ref of the built range
+inline uint32_t KdHost::divide(Sub& out, int32_t left, int32_t right, Box& box, int level) {
+    const int32_t count = right - left;
+    int32_t* ind = vind.data() + left;
+    if (count <= 10) {
+        // leaf: tight box of its points (nanoflann.hpp:862-879)
+        for (int d = 0; d < 3; ++d) box.lo[d] = box.hi[d] = at(ind[0], d);
+        for (int32_t k = 1; k < count; ++k)
+            for (int d = 0; d < 3; ++d) {
+                float v = at(ind[k], d);
+                if (box.lo[d] > v) box.lo[d] = v;
+                if (box.hi[d] < v) box.hi[d] = v;
+            }
+        const uint32_t base = 10u * out.n_leaves++;
+        out.pos_vert.resize((size_t)base + 10, -1);
+        for (int32_t k = 0; k < count; ++k) out.pos_vert[base + k] = ind[k];
+        return KD_LEAF_BIT | (base << 4) | (uint32_t)count;
+    }
+    if (level + 1 > out.depth) out.depth = level + 1;
+    float cut;
+    const Cut c = choose_and_partition(ind, count, box, cut);
+    // recurse; children return their tight boxes (nanoflann.hpp:889-903)
+    const uint32_t self = (uint32_t)out.nodes.size();
+    out.nodes.push_back({});
+    out.split.push_back(0u);
     Box lb = box, rb = box;
-    lb.hi[feat] = cut;
-    rb.lo[feat] = cut;
-    uint32_t r1 = divide(left, left + mid, lb, level + 1);
-    split[self] = 10u * n_leaves;  // first padded position of child 2
-    uint32_t r2 = divide(left + mid, right, rb, level + 1);
-    KdNodeH& nd = nodes[self];
-    nd.divlow = lb.hi[feat];
-    nd.divhigh = rb.lo[feat];
-    nd.ref1 = r1 | ((uint32_t)feat << KD_FEAT_SHIFT);
+    lb.hi[c.feat] = cut;
+    rb.lo[c.feat] = cut;
+    const uint32_t r1 = divide(out, left, left + c.mid, lb, level + 1);
+    out.split[self] = 10u * out.n_leaves;  // first padded position of child 2
+    const uint32_t r2 = divide(out, left + c.mid, right, rb, level + 1);
+    KdNodeH& nd = out.nodes[self];
+    nd.divlow = lb.hi[c.feat];
+    nd.divhigh = rb.lo[c.feat];
+    nd.ref1 = r1 | ((uint32_t)c.feat << KD_FEAT_SHIFT);
     nd.ref2 = r2;
     for (int d = 0; d < 3; ++d)
         nd.lo1[d] = lb.lo[d], nd.hi1[d] = lb.hi[d], nd.lo2[d] = rb.lo[d], nd.hi2[d] = rb.hi[d];
@@ -164,14 +206,76 @@ inline uint32_t KdHost::divide(int32_t left, int32_t right, Box& box, int level)
     return self;
 }
 
-inline void KdHost::build(const float* pts, uint32_t n) {
+// top levels: split here, build the two ranges concurrently (they touch disjoint parts of vind)
+inline void KdHost::divide_par(Sub& out, int32_t left, int32_t right, Box& box, int par_levels,
+                               int32_t cutoff) {
+    const int32_t count = right - left;
+    if (par_levels <= 0 || count <= cutoff || count <= 10) {
+        out.root = divide(out, left, right, box, 0);
+        out.total_nodes = (uint32_t)out.nodes.size();
+        out.total_leaves = out.n_leaves;
+        return;
+    }
+    float cut;
+    const Cut c = choose_and_partition(vind.data() + left, count, box, cut);
+    out.nodes.push_back({});
+    out.c1.reset(new Sub());
+    out.c2.reset(new Sub());
+    Box lb = box, rb = box;
+    lb.hi[c.feat] = cut;
+    rb.lo[c.feat] = cut;
+    auto fut = std::async(std::launch::async, [&]() {
+        divide_par(*out.c1, left, left + c.mid, lb, par_levels - 1, cutoff);
+    });
+    divide_par(*out.c2, left + c.mid, right, rb, par_levels - 1, cutoff);
+    fut.get();
+    KdNodeH& nd = out.nodes[0];
+    nd.divlow = lb.hi[c.feat];
+    nd.divhigh = rb.lo[c.feat];
+    nd.ref1 = (uint32_t)c.feat << KD_FEAT_SHIFT;  // child refs are set when spliced
+    nd.ref2 = 0;
+    for (int d = 0; d < 3; ++d)
+        nd.lo1[d] = lb.lo[d], nd.hi1[d] = lb.hi[d], nd.lo2[d] = rb.lo[d], nd.hi2[d] = rb.hi[d];
+    for (int d = 0; d < 3; ++d) {
+        box.lo[d] = lb.lo[d] < rb.lo[d] ? lb.lo[d] : rb.lo[d];
+        box.hi[d] = lb.hi[d] > rb.hi[d] ? lb.hi[d] : rb.hi[d];
+    }
+    out.total_nodes = 1 + out.c1->total_nodes + out.c2->total_nodes;
+    out.total_leaves = out.c1->total_leaves + out.c2->total_leaves;
+    out.depth = 1 + (out.c1->depth > out.c2->depth ? out.c1->depth : out.c2->depth);
+    out.root = 0;
+}
+
+// copy a built range into the global pre-order numbering
+inline void KdHost::splice(const Sub& s, uint32_t node_off, uint32_t leaf_off) {
+    if (s.c1) {
+        const uint32_t o1 = node_off + 1, o2 = o1 + s.c1->total_nodes;
+        const uint32_t l2 = leaf_off + s.c1->total_leaves;
+        KdNodeH nd = s.nodes[0];
+        nd.ref1 |= shift_ref(s.c1->root, o1, leaf_off);
+        nd.ref2 = shift_ref(s.c2->root, o2, l2);
+        nodes[node_off] = nd;
+        split[node_off] = 10u * l2;
+        splice(*s.c1, o1, leaf_off);
+        splice(*s.c2, o2, l2);
+        return;
+    }
+    for (size_t i = 0; i < s.nodes.size(); ++i) {
+        KdNodeH nd = s.nodes[i];
+        nd.ref1 = shift_ref(nd.ref1, node_off, leaf_off);
+        nd.ref2 = shift_ref(nd.ref2, node_off, leaf_off);
+        nodes[node_off + i] = nd;
+        split[node_off + i] = s.split[i] + 10u * leaf_off;
+    }
+    for (size_t i = 0; i < s.pos_vert.size(); ++i) pos_vert[10 * (size_t)leaf_off + i] = s.pos_vert[i];
+}
+
+inline void KdHost::build(const float* pts, uint32_t n, int threads) {
     p_ = pts;
     vind.resize(n);
     for (uint32_t i = 0; i < n; ++i) vind[i] = (int32_t)i;
     nodes.clear();
-    nodes.reserve(n / 4 + 8);
     split.clear();
-    split.reserve(n / 4 + 8);
     pos_vert.clear();
     n_leaves = 0;
     depth = 0;
@@ -187,7 +291,20 @@ inline void KdHost::build(const float* pts, uint32_t n) {
             if (v > box.hi[d]) box.hi[d] = v;
         }
     for (int d = 0; d < 3; ++d) bbox[d] = box.lo[d], bbox[d + 3] = box.hi[d];
-    root_ref = divide(0, (int32_t)n, box, 0);
+    int par_levels = 0;
+    if (threads > 1 && n >= 20000) {
+        while ((1 << par_levels) < threads && par_levels < 6) ++par_levels;
+        ++par_levels;  // ranges are uneven: a few more tasks than threads
+    }
+    Sub top;
+    divide_par(top, 0, (int32_t)n, box, par_levels, (int32_t)(n / 64 + 1024));
+    nodes.resize(top.total_nodes);
+    split.resize(top.total_nodes);
+    pos_vert.assign(10 * (size_t)top.total_leaves, -1);
+    splice(top, 0, 0);
+    n_leaves = top.total_leaves;
+    depth = top.depth;
+    root_ref = top.c1 ? 0u : top.root;
 }
 
 }  // namespace sdfk

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <random>
@@ -1257,6 +1258,7 @@ struct sdfhip_ctx {
     uint32_t* d_amb_s1 = nullptr;
     uint32_t* d_amb_s2 = nullptr;
     int64_t opt_packet = 1;
+    int64_t opt_build_threads = 1;
     uint32_t* d_adj_off = nullptr;
     int32_t* d_adj_faces = nullptr;
     float4* d_geo = nullptr;
@@ -1400,7 +1402,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = h->stream;
     // strict kd-tree on the host (sdf.cpp:32 kd_tree.rebuild())
-    h->kd.build(h->h_verts, h->nv);
+    h->kd.build(h->h_verts, h->nv, (int)h->opt_build_threads);
     auto t1 = std::chrono::steady_clock::now();
     h->last_kd_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
     std::memcpy(h->aabb, h->kd.bbox, sizeof(h->aabb));  // sdf.cpp:36-37
@@ -1760,6 +1762,14 @@ int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32
     h->robust = robust != 0;
     h->own = copy != 0;
     h->nv = nv, h->nf = nf;
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (const char* e = getenv("OMP_NUM_THREADS")) {
+            const int v = atoi(e);
+            if (v > 0 && (unsigned)v < hw) hw = (unsigned)v;
+        }
+        h->opt_build_threads = hw < 1 ? 1 : (hw > 16 ? 16 : hw);
+    }
     if (copy) {
         h->owned_verts.assign(verts, verts + 3 * (size_t)nv);
         h->owned_faces.assign(faces, faces + 3 * (size_t)nf);
@@ -2013,6 +2023,8 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_profile = v;
         if (v == 2) h->prof_ms = 0.0, h->prof_launches = 0, h->prof_points = 0;  // reset
     }
+    else if (!strcmp(key, "build_threads"))
+        h->opt_build_threads = v < 1 ? 1 : v;
     else if (!strcmp(key, "packet"))
         h->opt_packet = v;
     else if (!strcmp(key, "sort_min"))

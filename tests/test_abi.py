@@ -89,3 +89,12 @@ def test_cpp_facade_compiles_and_fails_loudly_without_gpu(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
     else:
         assert r.returncode == 3 and "no HIP device" in r.stdout
+
+
+def test_parallel_kd_build_is_identical_to_serial(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "kdchk")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread",
+                           os.path.join(ROOT, "tests", "cpp", "kd_build_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
