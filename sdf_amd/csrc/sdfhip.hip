@@ -1081,11 +1081,20 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, i
             hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
         }
     }
-    if ((threadIdx.x & 63) == 0) {
-        for (int d = 0; d < 3; ++d) {
-            atomicMin(&b[d], f2ord(lo[d]));
-            atomicMax(&b[3 + d], f2ord(hi[d]));
-        }
+    // one set of atomics per block (they all hit the same six words)
+    __shared__ float red[4][6];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int d = 0; d < 3; ++d) red[w][d] = lo[d], red[w][3 + d] = hi[d];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        float v = red[0][d];
+        for (int k = 1; k < 4; ++k) v = d < 3 ? fminf(v, red[k][d]) : fmaxf(v, red[k][d]);
+        if (d < 3)
+            atomicMin(&b[d], f2ord(v));
+        else
+            atomicMax(&b[d], f2ord(v));
     }
 }
 __global__ void k_query_morton(const float* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ b,
@@ -1602,7 +1611,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         const uint32_t* perm = nullptr;
         if (h->opt_sort && m >= h->opt_sort_min) {
             k_bounds_init<<<1, 64, 0, s>>>(h->d_qbounds);
-            const int nb = (int)((m / 4 + 255) / 256 < 4096 ? (m / 4 + 255) / 256 + 1 : 4096);
+            const int nb = (int)((m / 4 + 255) / 256 < 1024 ? (m / 4 + 255) / 256 + 1 : 1024);
             k_bounds<<<nb, 256, 0, s>>>(p, m, h->d_qbounds);
             k_query_morton<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(p, (uint32_t)m, h->d_qbounds,
                                                                        h->d_qkeys);
