@@ -319,6 +319,64 @@ __device__ __forceinline__ int ray_x_pos(const MeshDev& M, V3 q) {
     return c;
 }
 
+// Wave-cooperative form of ray_z_pair for 64 Morton-adjacent queries: the threaded walk is
+// wave-uniform (a node is entered when ANY lane's point is inside its xy box; nodes and faces
+// come in by scalar loads) and each lane applies the exact per-face predicate to the leaves
+// whose box it is inside.  XOR parity is order independent and lanes only count faces that pass
+// their own Overlap test, so the result per lane equals ray_z_pair's.
+__device__ __forceinline__ void ray_z_pair_packet(const MeshDev& M, V3 q, bool active, int& zp, int& zm) {
+    zp = 0;
+    zm = 0;
+    uint32_t i = 0;
+    const uint32_t n = M.n_rnodes;
+    while (i < n) {
+        i = __builtin_amdgcn_readfirstlane(i);
+        const float4 a = M.rnodes[2 * (size_t)i];
+        const float4 b = M.rnodes[2 * (size_t)i + 1];
+        const bool hit = active && !(q.x > a.z || a.x > q.x) && !(q.y > a.w || a.y > q.y);
+        const uint32_t skip = __float_as_uint(b.z), face = __float_as_uint(b.w);
+        if (__ballot(hit) == 0ull) {
+            i = skip;
+            continue;
+        }
+        if (face != NOFACE) {
+            const float4 f0 = M.rface[3 * (size_t)face];      // a'.xyz b'.x
+            const float4 f1 = M.rface[3 * (size_t)face + 1];  // b'.yz c'.xy
+            const float4 f2 = M.rface[3 * (size_t)face + 2];  // c'.z n'.xyz
+            if (hit) {
+                const bool okp = !(q.z > b.y || b.x > FLT_MAX);
+                const bool okm = !(-FLT_MAX > b.y || b.x > q.z);
+                const V3 nr = {f2.y, f2.z, f2.w};
+                const V3 dv = sdfk::sub(q, V3{f0.x, f0.y, f0.z});
+                const float s = sdfk::dot(nr, dv) * nr.z;
+                const bool pos = s > 0.f;
+                if (pos ? okm : okp) {
+                    if (sdfk::bary2d_inside(q.x, q.y, f0.x, f0.y, f0.w, f1.x, f1.z, f1.w)) {
+                        if (pos)
+                            zm ^= 1;
+                        else
+                            zp ^= 1;
+                    }
+                }
+            }
+        }
+        i = i + 1;
+    }
+}
+
+// _raycast for a whole wave; lanes with valid == false take no part
+__device__ __forceinline__ float raycast_packet(const MeshDev& M, V3 p, bool valid) {
+    const bool inbox = valid && !(p.x < M.bb[0] || p.x > M.bb[3] || p.y < M.bb[1] || p.y > M.bb[4] ||
+                                  p.z < M.bb[2] || p.z > M.bb[5]);  // sdf.cpp:278-283
+    if (__ballot(inbox) == 0ull) return -1.f;
+    const V3 q = sdfk::mulR(p, M.R);
+    int zp, zm;
+    ray_z_pair_packet(M, q, inbox, zp, zm);
+    int result = zp + zm;
+    if (inbox && result == 1) result += ray_x_pos(M, q);  // tiebreaker (sdf.cpp:326), rare
+    return (inbox && result > 1) ? 1.0f : -1.0f;
+}
+
 // returns +1 / -1 (sdf.cpp:327); detail (optional) = {z+, z-, x+|-1}
 __device__ __forceinline__ float raycast(const MeshDev& M, V3 p, int* detail) {
     if (detail) detail[0] = detail[1] = detail[2] = -1;
@@ -680,7 +738,12 @@ __global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float*
     const int64_t src = perm ? (int64_t)perm[ic] : ic;
     const V3 p = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
     float sign = 0.f;
-    if (ROBUST && KIND != Q_NN && valid) sign = raycast(M, p, nullptr);  // sdf.cpp:110
+    if (ROBUST && KIND != Q_NN) sign = raycast_packet(M, p, valid);  // sdf.cpp:110
+    if (ROBUST && KIND == Q_CONTAINS) {  // sdf.cpp:163-169: no nearest-vertex search at all
+        if (valid) ((uint8_t*)out)[src] = sign >= 0.0f;
+        if ((threadIdx.x & 63) == 0) amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
+        return;
+    }
     const PacketBest pb = kd_nearest_packet(M, p.x, p.y, p.z, stk);
     // pb.h is nanoflann's answer iff nanoflann does not prune it before visiting it:
     //  (1) no other vertex within b * c (c - 1 ~ 4.5e-6): impossible, see k_query_packet header;
@@ -1584,7 +1647,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     const bool needs_kd = !(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST));
     const uint32_t depth = (uint32_t)(h->kd.depth > 0 ? h->kd.depth : 1);
     const bool sort_any = h->opt_sort && n >= h->opt_sort_min;
-    const bool packet_any = sort_any && needs_kd && h->opt_packet && depth < 4096;
+    const bool packet_any = sort_any && KIND != Q_DETAIL && h->opt_packet && depth < 4096;
     const int64_t fb_cap = packet_any ? (n < (1ll << 27) ? n : (1ll << 27)) : 0;
     if (sort_any)
         if (int rc = reserve_query_ws(h, n < chunk ? n : chunk, fb_cap)) return rc;
