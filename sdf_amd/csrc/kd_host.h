@@ -44,6 +44,19 @@ struct KdNodeH {  // 64 B
 };
 static_assert(sizeof(KdNodeH) == 64, "device layout");
 
+// Two binary levels collapsed into one 4-wide node for the packet pass (half as many dependent
+// load -> test -> branch steps per query wave).  Slots 0,1 come from binary child 1 (its two
+// children, or itself in slot 0 if it is a leaf), slots 2,3 from child 2; an unused slot has
+// an inverted infinite box, whose lower bound is +inf.  Search-order data (divlow/divhigh)
+// is not needed here: the packet pass orders children by their box distances and settles
+// ties on the binary tree.
+struct KdQuadH {  // 128 B
+    float box[4][6];  // lo xyz, hi xyz
+    uint32_t ref[4];  // quad node index, or a leaf ref (bit 31) exactly as in KdNodeH
+    uint32_t pad[4];
+};
+static_assert(sizeof(KdQuadH) == 128, "device layout");
+
 constexpr uint32_t KD_LEAF_BIT = 0x80000000u;
 constexpr uint32_t KD_FEAT_SHIFT = 29;
 constexpr uint32_t KD_REF_MASK = 0x1FFFFFFFu;  // strips leaf bit and feat bits
@@ -59,8 +72,13 @@ struct KdHost {
     int depth = 0;                    // max internal nodes on a root-to-leaf path
     float bbox[6] = {0, 0, 0, 0, 0, 0};  // min xyz, max xyz (= mesh AABB, sdf.cpp:36-37)
 
+    std::vector<KdQuadH> quads;  // 4-wide collapse of `nodes`, DFS pre-order
+    uint32_t quad_root = KD_LEAF_BIT;
+    int quad_depth = 0;
+
     // threads <= 1: serial.  Otherwise up to ~2*threads ranges are built concurrently.
     void build(const float* pts, uint32_t n, int threads = 0);
+    void build_quads();
 
    private:
     struct Box {
@@ -88,6 +106,7 @@ struct KdHost {
     uint32_t divide(Sub& out, int32_t left, int32_t right, Box& box, int level);
     void divide_par(Sub& out, int32_t left, int32_t right, Box& box, int par_levels, int32_t cutoff);
     void splice(const Sub& s, uint32_t node_off, uint32_t leaf_off);
+    uint32_t quad_of(uint32_t ref, int level);
     static uint32_t shift_ref(uint32_t ref, uint32_t node_off, uint32_t leaf_off) {
         const uint32_t feat = ref & (3u << KD_FEAT_SHIFT);
         if (ref & KD_LEAF_BIT) {
@@ -305,6 +324,55 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads) {
     n_leaves = top.total_leaves;
     depth = top.depth;
     root_ref = top.c1 ? 0u : top.root;
+}
+
+inline uint32_t KdHost::quad_of(uint32_t ref, int level) {
+    ref &= ~(3u << KD_FEAT_SHIFT);
+    if (ref & KD_LEAF_BIT) return ref;
+    if (level + 1 > quad_depth) quad_depth = level + 1;
+    const uint32_t self = (uint32_t)quads.size();
+    quads.push_back({});
+    const float inf = __builtin_inff();
+    KdQuadH q;
+    for (int k = 0; k < 4; ++k) {
+        for (int d = 0; d < 3; ++d) q.box[k][d] = inf, q.box[k][3 + d] = -inf;
+        q.ref[k] = 0;
+        q.pad[k] = 0;
+    }
+    const KdNodeH nd = nodes[ref];
+    const uint32_t child[2] = {nd.ref1 & ~(3u << KD_FEAT_SHIFT), nd.ref2};
+    const float* cbox[2][2] = {{nd.lo1, nd.hi1}, {nd.lo2, nd.hi2}};
+    uint32_t gref[4] = {0, 0, 0, 0};
+    bool used[4] = {false, false, false, false};
+    for (int side = 0; side < 2; ++side) {
+        if (child[side] & KD_LEAF_BIT) {
+            const int k = 2 * side;
+            for (int d = 0; d < 3; ++d) q.box[k][d] = cbox[side][0][d], q.box[k][3 + d] = cbox[side][1][d];
+            gref[k] = child[side];
+            used[k] = true;
+        } else {
+            const KdNodeH c = nodes[child[side]];
+            const int k = 2 * side;
+            for (int d = 0; d < 3; ++d) {
+                q.box[k][d] = c.lo1[d], q.box[k][3 + d] = c.hi1[d];
+                q.box[k + 1][d] = c.lo2[d], q.box[k + 1][3 + d] = c.hi2[d];
+            }
+            gref[k] = c.ref1 & ~(3u << KD_FEAT_SHIFT);
+            gref[k + 1] = c.ref2;
+            used[k] = used[k + 1] = true;
+        }
+    }
+    for (int k = 0; k < 4; ++k)
+        if (used[k]) q.ref[k] = quad_of(gref[k], level + 1);
+    quads[self] = q;
+    return self;
+}
+
+inline void KdHost::build_quads() {
+    quads.clear();
+    quads.reserve(nodes.size() / 2 + 8);
+    quad_depth = 0;
+    quad_root = quad_of(root_ref, 0);
 }
 
 }  // namespace sdfk

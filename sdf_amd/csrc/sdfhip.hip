@@ -73,6 +73,8 @@ struct MeshDev {
     // vertex kd-tree: 64 B nodes {box1 lo/hi, box2 lo/hi, divlow, divhigh, ref1|feat, ref2}
     const float4* kd_pn;
     const uint32_t* kd_split;
+    const float4* kd_qn;  // 4-wide collapse for the packet pass: 128 B {box[4][6], ref[4], pad}
+    uint32_t kd_qroot;
     const float* kd_pts;
     const int32_t* kd_vind;
     uint32_t kd_root;
@@ -599,33 +601,49 @@ __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float 
     uint32_t b = 0x7F7FFFFFu, s2 = 0x7F7FFFFFu;  // FLT_MAX bits (KNNResultSet::init)
     int h = -1;
     const float c = M.amb_c2;  // everything within best * c^2 is evaluated
-    uint32_t cur = M.kd_root;
+    uint32_t cur = M.kd_qroot;
     int sp = 0;
     for (;;) {
         cur = __builtin_amdgcn_readfirstlane(cur);
         bool need_pop = false;
         if (!(cur & KD_LEAF)) {
-            const float* pn = (const float*)(M.kd_pn + 4 * (size_t)cur);  // 16 dwords, scalar load
+            // 4-wide node: 32 dwords by scalar load; slots 0,1 / 2,3 are the two binary sides
+            const float* Q = (const float*)(M.kd_qn + 8 * (size_t)cur);
             const float thr = __uint_as_float(b) * c;
-            const float lb1 = box_lb(qx, qy, qz, pn[0], pn[1], pn[2], pn[3], pn[4], pn[5]);
-            const float lb2 = box_lb(qx, qy, qz, pn[6], pn[7], pn[8], pn[9], pn[10], pn[11]);
-            const unsigned long long m1 = __ballot(lb1 <= thr), m2 = __ballot(lb2 <= thr);
-            const uint32_t ndz = __float_as_uint(pn[14]);
-            const uint32_t r1 = ndz & ~KD_FEATM, r2 = __float_as_uint(pn[15]);
-            if (m1 != 0ull && m2 != 0ull) {
-                // order: the child most lanes call "near" (nanoflann.hpp:1371-1387)
-                const uint32_t feat = (ndz >> sdfk::KD_FEAT_SHIFT) & 3u;
-                const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
-                const bool lowside = ((val - pn[12]) + (val - pn[13])) < 0;
-                const bool first1 = __popcll(__ballot(lowside)) >= 32;
-                stk[sp++] = (cur << 1) | (first1 ? 1u : 0u);  // deferred child: 1 = child2
-                cur = first1 ? r1 : r2;
-            } else if (m1 != 0ull) {
-                cur = r1;
-            } else if (m2 != 0ull) {
-                cur = r2;
-            } else {
+            const float lb0 = box_lb(qx, qy, qz, Q[0], Q[1], Q[2], Q[3], Q[4], Q[5]);
+            const float lb1 = box_lb(qx, qy, qz, Q[6], Q[7], Q[8], Q[9], Q[10], Q[11]);
+            const float lb2 = box_lb(qx, qy, qz, Q[12], Q[13], Q[14], Q[15], Q[16], Q[17]);
+            const float lb3 = box_lb(qx, qy, qz, Q[18], Q[19], Q[20], Q[21], Q[22], Q[23]);
+            const uint32_t act = (__ballot(lb0 <= thr) != 0ull ? 1u : 0u) |
+                                 (__ballot(lb1 <= thr) != 0ull ? 2u : 0u) |
+                                 (__ballot(lb2 <= thr) != 0ull ? 4u : 0u) |
+                                 (__ballot(lb3 <= thr) != 0ull ? 8u : 0u);
+            if (act == 0u) {
                 need_pop = true;
+            } else {
+                // visiting order by box distance, majority vote per comparison (any order is
+                // exact; nearer first tightens `b` sooner)
+                uint32_t seq;  // four 2-bit slot ids, nearest in the low bits
+                if ((act & (act - 1u)) == 0u) {
+                    seq = (uint32_t)__builtin_ctz(act) * 0x55u;  // single active slot
+                } else {
+                    const bool a_first = __popcll(__ballot(fminf(lb0, lb1) <= fminf(lb2, lb3))) >= 32;
+                    const bool s01 = __popcll(__ballot(lb0 <= lb1)) >= 32;
+                    const bool s23 = __popcll(__ballot(lb2 <= lb3)) >= 32;
+                    const uint32_t pa = s01 ? (0u | 1u << 2) : (1u | 0u << 2);
+                    const uint32_t pb = s23 ? (2u | 3u << 2) : (3u | 2u << 2);
+                    seq = a_first ? (pa | pb << 4) : (pb | pa << 4);
+                }
+                int pend = -1;
+#pragma unroll
+                for (int k = 3; k >= 0; --k) {
+                    const uint32_t sl = (seq >> (2 * k)) & 3u;
+                    if ((act >> sl) & 1u) {
+                        if (pend >= 0 && (uint32_t)pend != sl) stk[sp++] = (cur << 2) | (uint32_t)pend;
+                        pend = (int)sl;
+                    }
+                }
+                cur = __float_as_uint(Q[24 + pend]);
             }
         } else {
             const uint32_t left = (cur & sdfk::KD_REF_MASK) >> 4, cnt = cur & 15u;
@@ -650,8 +668,8 @@ __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float 
                 // nanoflann's order and settle each exact tie by DFS order.
                 b = b0, s2 = s0, h = h0;
                 for (uint32_t k = 0; k < cnt; ++k) {
-                    const float4 Q = P[k];
-                    const float dx = qx - Q.x, dy = qy - Q.y, dz = qz - Q.z;
+                    const float4 Qp = P[k];
+                    const float dx = qx - Qp.x, dy = qy - Qp.y, dz = qz - Qp.z;
                     const uint32_t du = __float_as_uint((dx * dx + dy * dy) + dz * dz);
                     const int idx = (int)(left + k);
                     if (du == b && h >= 0 && !(h >= (int)left && h < idx))  // holder in another leaf
@@ -669,12 +687,12 @@ __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float 
             for (;;) {
                 if (sp == 0) return PacketBest{__uint_as_float(b), __uint_as_float(s2), h};
                 const uint32_t e = __builtin_amdgcn_readfirstlane(stk[--sp]);
-                const uint32_t parent = e >> 1, which = e & 1u;
-                const float* pn = (const float*)(M.kd_pn + 4 * (size_t)parent);
-                const float* bx = pn + 6 * which;
+                const uint32_t parent = e >> 2, sl = e & 3u;
+                const float* Q = (const float*)(M.kd_qn + 8 * (size_t)parent);
+                const float* bx = Q + 6 * sl;
                 const float lb = box_lb(qx, qy, qz, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]);
                 if (__ballot(lb <= __uint_as_float(b) * c) != 0ull) {
-                    cur = which ? __float_as_uint(pn[15]) : (__float_as_uint(pn[14]) & ~KD_FEATM);
+                    cur = __float_as_uint(Q[24 + sl]);
                     break;
                 }
             }
@@ -729,7 +747,7 @@ __global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float*
                                                          uint32_t* __restrict__ amb_cnt,
                                                          uint32_t depth_cap) {
     extern __shared__ uint32_t lds[];
-    uint32_t* stk = lds + (threadIdx.x >> 6) * (depth_cap + 1);
+    uint32_t* stk = lds + (threadIdx.x >> 6) * depth_cap;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     // lanes past the end of the batch repeat its last query (and write nothing): they then ask
@@ -1315,6 +1333,8 @@ struct sdfhip_ctx {
     float* d_verts = nullptr;
     uint32_t* d_faces = nullptr;
     float4* d_kd_pn = nullptr;
+    float4* d_kd_qn = nullptr;
+    size_t kd_quads_cap = 0;
     uint32_t* d_kd_split = nullptr;
     float* d_kd_pts = nullptr;
     int32_t* d_kd_vind = nullptr;
@@ -1477,7 +1497,12 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     h->kd.build(h->h_verts, h->nv, (int)h->opt_build_threads);
     auto t1 = std::chrono::steady_clock::now();
     h->last_kd_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    h->kd.build_quads();
     std::memcpy(h->aabb, h->kd.bbox, sizeof(h->aabb));  // sdf.cpp:36-37
+    if (h->kd.quads.size() > h->kd_quads_cap) {
+        if (int rc = dalloc(&h->d_kd_qn, 8 * h->kd.quads.size())) return rc;
+        h->kd_quads_cap = h->kd.quads.size();
+    }
     if (h->kd.nodes.size() >= (size_t)KD_MARK)
         return fail(SDFHIP_E_INVALID, "kd-tree too large");
     if (h->kd.nodes.size() > h->kd_nodes_cap) {
@@ -1528,6 +1553,8 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
                             hipMemcpyHostToDevice, s));
         HIPC(hipMemcpyAsync(h->d_kd_split, h->kd.split.data(), sizeof(uint32_t) * h->kd.split.size(),
                             hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(h->d_kd_qn, h->kd.quads.data(), sizeof(sdfk::KdQuadH) * h->kd.quads.size(),
+                            hipMemcpyHostToDevice, s));
     }
     HIPC(hipStreamSynchronize(s));  // perm_pts is pageable and about to go out of scope
     if (h->robust && draw_R && !h->R_pinned) draw_rotation(h);
@@ -1542,6 +1569,8 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     MeshDev M;
     M.kd_pn = h->d_kd_pn;
     M.kd_split = h->d_kd_split;
+    M.kd_qn = h->d_kd_qn;
+    M.kd_qroot = h->kd.quad_root;
     M.kd_pts = h->d_kd_pts;
     M.kd_vind = h->d_kd_vind;
     M.kd_root = h->kd.root_ref;
@@ -1644,7 +1673,6 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     const MeshDev M = mesh_view(h);
     const size_t osz = KIND == Q_CONTAINS ? 1 : (KIND == Q_DETAIL ? 12 : 4);
     const int64_t chunk = h->opt_chunk > 0 ? h->opt_chunk : (1 << 24);
-    const bool needs_kd = !(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST));
     const uint32_t depth = (uint32_t)(h->kd.depth > 0 ? h->kd.depth : 1);
     const bool sort_any = h->opt_sort && n >= h->opt_sort_min;
     const bool packet_any = sort_any && KIND != Q_DETAIL && h->opt_packet && depth < 4096;
@@ -1686,12 +1714,14 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         if (perm && packet_any) {
             if (deferred_pts + m > h->fb_cap)
                 if (int rc = flush()) return rc;
-            const size_t lds = (size_t)(PBLOCK / 64) * (depth + 1) * sizeof(uint32_t);
+            // packet stack: <= 3 deferred slots per 4-wide level
+            const uint32_t pstack = 3u * (uint32_t)(h->kd.quad_depth > 0 ? h->kd.quad_depth : 1) + 4u;
+            const size_t lds = (size_t)(PBLOCK / 64) * pstack * sizeof(uint32_t);
             constexpr int PK = KIND == Q_DETAIL ? Q_NN : KIND;
             ProfScope prof{h, s};  // the dominant kernel, one event pair per launch
             if (int rc = prof.begin()) return rc;
             k_query_packet<PK, ROBUST><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, lds, s>>>(
-                M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, depth);
+                M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, pstack);
             if (int rc = prof.end(m)) return rc;
             exclusive_scan_u32(h->d_amb_cnt, (uint32_t)((m + 63) / 64), h->d_amb_s1, h->d_amb_s2, s);
             k_fb_compact<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(
@@ -1914,7 +1944,7 @@ void sdfhip_destroy(sdfhip_t* h) {
     if (!h) return;
     DevGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_pts, h->d_kd_vind, h->d_adj_off,
+    void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_qn, h->d_kd_pts, h->d_kd_vind, h->d_adj_off,
                     h->d_adj_faces, h->d_geo, h->d_rface, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
