@@ -10,9 +10,12 @@
 //
 //   * points are stored in permuted ("vind") order, so a leaf is a contiguous run and
 //     the traversal needs no index indirection; `pos_vert` maps the winner back once.
-//     Tree positions are PADDED: leaf j owns positions [10 j, 10 j + 10), of which the first
-//     `count` hold its vertices in nanoflann's order and the rest a far-away sentinel
-//     (pos_vert = -1), so that a whole leaf can be evaluated as ten straight-line slots.
+//     Tree positions are PADDED per packet group: a maximal subtree with <= group_max
+//     vertices ("group"; every leaf lies in exactly one) owns a block of positions that
+//     starts at a multiple of 4 and spans ceil(count / 4) * 4 slots.  Its leaves sit in it
+//     back to back in nanoflann's order; the tail slots hold a far-away sentinel
+//     (pos_vert = -1).  The packet pass evaluates a group as straight-line chunks of four
+//     slots (one 64-byte scalar load each); the strict search only ever sees the leaves.
 //   * only internal nodes are materialised, 64 B each (one s_load_dwordx16 / four dwordx4):
 //         { box1.lo[3], box1.hi[3], box2.lo[3], box2.hi[3],      tight boxes of the children
 //           divlow, divhigh, ref1 | feat<<29, ref2 }
@@ -52,7 +55,7 @@ static_assert(sizeof(KdNodeH) == 64, "device layout");
 // ties on the binary tree.
 struct KdQuadH {  // 128 B
     float box[4][6];  // lo xyz, hi xyz
-    uint32_t ref[4];  // quad node index, or a leaf ref (bit 31) exactly as in KdNodeH
+    uint32_t ref[4];  // quad node index, or with bit 31 a packet group: (first pos / 4) << 4 | chunks
     uint32_t pad[4];
 };
 static_assert(sizeof(KdQuadH) == 128, "device layout");
@@ -60,12 +63,13 @@ static_assert(sizeof(KdQuadH) == 128, "device layout");
 constexpr uint32_t KD_LEAF_BIT = 0x80000000u;
 constexpr uint32_t KD_FEAT_SHIFT = 29;
 constexpr uint32_t KD_REF_MASK = 0x1FFFFFFFu;  // strips leaf bit and feat bits
-constexpr uint32_t KD_MAX_POINTS = 1u << 23;   // padded positions (<= 10 per vertex) fit 25 bits
+constexpr uint32_t KD_MAX_POINTS = 1u << 23;   // padded positions (< 4 per vertex) fit 25 bits
+constexpr uint32_t KD_GROUP_LIMIT = 60;        // chunks of a group fit 4 bits
 
 struct KdHost {
     std::vector<int32_t> vind;      // nanoflann's permutation (dense, size n)
     std::vector<int32_t> pos_vert;  // padded tree position -> vertex index, -1 = sentinel slot
-    uint32_t n_leaves = 0;
+    uint32_t group_max = 16;        // vertices per packet group (10 = one group per leaf)
     std::vector<KdNodeH> nodes;
     std::vector<uint32_t> split;  // parallel to nodes
     uint32_t root_ref = KD_LEAF_BIT;  // empty leaf
@@ -89,12 +93,12 @@ struct KdHost {
         std::vector<KdNodeH> nodes;
         std::vector<uint32_t> split;
         std::vector<int32_t> pos_vert;
-        uint32_t n_leaves = 0;
+        uint32_t npos = 0;  // position cursor; a multiple of 4 outside an open group
         uint32_t root = KD_LEAF_BIT;
         int depth = 0;
         // task-parallel inner node: nodes.size() == 1 (refs still to be set), children below
         std::unique_ptr<Sub> c1, c2;
-        uint32_t total_nodes = 0, total_leaves = 0;
+        uint32_t total_nodes = 0, total_pos = 0;
     };
     struct Cut {
         int feat;
@@ -103,15 +107,22 @@ struct KdHost {
     const float* p_ = nullptr;
     float at(int32_t i, int d) const { return p_[3 * (size_t)i + d]; }
     Cut choose_and_partition(int32_t* ind, int32_t count, const Box& box, float& cutval) const;
-    uint32_t divide(Sub& out, int32_t left, int32_t right, Box& box, int level);
+    uint32_t divide(Sub& out, int32_t left, int32_t right, Box& box, int level, bool in_group);
     void divide_par(Sub& out, int32_t left, int32_t right, Box& box, int par_levels, int32_t cutoff);
-    void splice(const Sub& s, uint32_t node_off, uint32_t leaf_off);
+    void splice(const Sub& s, uint32_t node_off, uint32_t pos_off);
     uint32_t quad_of(uint32_t ref, int level);
-    static uint32_t shift_ref(uint32_t ref, uint32_t node_off, uint32_t leaf_off) {
+    std::vector<uint32_t> sub_first_, sub_count_;  // per binary node: first position, vertices
+    void subtree_extent(uint32_t ref, uint32_t& first, uint32_t& count) const {
+        if (ref & KD_LEAF_BIT)
+            first = (ref & KD_REF_MASK) >> 4, count = ref & 15u;
+        else
+            first = sub_first_[ref & KD_REF_MASK], count = sub_count_[ref & KD_REF_MASK];
+    }
+    static uint32_t shift_ref(uint32_t ref, uint32_t node_off, uint32_t pos_off) {
         const uint32_t feat = ref & (3u << KD_FEAT_SHIFT);
         if (ref & KD_LEAF_BIT) {
             const uint32_t cnt = ref & 15u, pos = (ref & KD_REF_MASK) >> 4;
-            return KD_LEAF_BIT | feat | ((pos + 10u * leaf_off) << 4) | cnt;
+            return KD_LEAF_BIT | feat | ((pos + pos_off) << 4) | cnt;
         }
         return feat | ((ref & KD_REF_MASK) + node_off);
     }
@@ -181,9 +192,18 @@ inline KdHost::Cut KdHost::choose_and_partition(int32_t* ind, int32_t count, con
 }
 
 // serial recursion into `out` (local numbering); returns the ref of the built range
-inline uint32_t KdHost::divide(Sub& out, int32_t left, int32_t right, Box& box, int level) {
+inline uint32_t KdHost::divide(Sub& out, int32_t left, int32_t right, Box& box, int level,
+                               bool in_group) {
     const int32_t count = right - left;
     int32_t* ind = vind.data() + left;
+    if (!in_group && count <= (int32_t)group_max) {
+        // this subtree is one packet group: its leaves take consecutive positions, the block is
+        // closed (sentinel-filled to a multiple of 4) when the subtree is done
+        const uint32_t r = divide(out, left, right, box, level, true);
+        out.npos = (out.npos + 3u) & ~3u;
+        out.pos_vert.resize(out.npos, -1);
+        return r;
+    }
     if (count <= 10) {
         // leaf: tight box of its points (nanoflann.hpp:862-879)
         for (int d = 0; d < 3; ++d) box.lo[d] = box.hi[d] = at(ind[0], d);
@@ -193,8 +213,9 @@ inline uint32_t KdHost::divide(Sub& out, int32_t left, int32_t right, Box& box, 
                 if (box.lo[d] > v) box.lo[d] = v;
                 if (box.hi[d] < v) box.hi[d] = v;
             }
-        const uint32_t base = 10u * out.n_leaves++;
-        out.pos_vert.resize((size_t)base + 10, -1);
+        const uint32_t base = out.npos;
+        out.npos += (uint32_t)count;
+        out.pos_vert.resize(out.npos, -1);
         for (int32_t k = 0; k < count; ++k) out.pos_vert[base + k] = ind[k];
         return KD_LEAF_BIT | (base << 4) | (uint32_t)count;
     }
@@ -208,9 +229,9 @@ inline uint32_t KdHost::divide(Sub& out, int32_t left, int32_t right, Box& box, 
     Box lb = box, rb = box;
     lb.hi[c.feat] = cut;
     rb.lo[c.feat] = cut;
-    const uint32_t r1 = divide(out, left, left + c.mid, lb, level + 1);
-    out.split[self] = 10u * out.n_leaves;  // first padded position of child 2
-    const uint32_t r2 = divide(out, left + c.mid, right, rb, level + 1);
+    const uint32_t r1 = divide(out, left, left + c.mid, lb, level + 1, in_group);
+    out.split[self] = out.npos;  // first padded position of child 2
+    const uint32_t r2 = divide(out, left + c.mid, right, rb, level + 1, in_group);
     KdNodeH& nd = out.nodes[self];
     nd.divlow = lb.hi[c.feat];
     nd.divhigh = rb.lo[c.feat];
@@ -229,10 +250,10 @@ inline uint32_t KdHost::divide(Sub& out, int32_t left, int32_t right, Box& box, 
 inline void KdHost::divide_par(Sub& out, int32_t left, int32_t right, Box& box, int par_levels,
                                int32_t cutoff) {
     const int32_t count = right - left;
-    if (par_levels <= 0 || count <= cutoff || count <= 10) {
-        out.root = divide(out, left, right, box, 0);
+    if (par_levels <= 0 || count <= cutoff || count <= (int32_t)KD_GROUP_LIMIT) {
+        out.root = divide(out, left, right, box, 0, false);
         out.total_nodes = (uint32_t)out.nodes.size();
-        out.total_leaves = out.n_leaves;
+        out.total_pos = out.npos;
         return;
     }
     float cut;
@@ -260,33 +281,33 @@ inline void KdHost::divide_par(Sub& out, int32_t left, int32_t right, Box& box, 
         box.hi[d] = lb.hi[d] > rb.hi[d] ? lb.hi[d] : rb.hi[d];
     }
     out.total_nodes = 1 + out.c1->total_nodes + out.c2->total_nodes;
-    out.total_leaves = out.c1->total_leaves + out.c2->total_leaves;
+    out.total_pos = out.c1->total_pos + out.c2->total_pos;
     out.depth = 1 + (out.c1->depth > out.c2->depth ? out.c1->depth : out.c2->depth);
     out.root = 0;
 }
 
 // copy a built range into the global pre-order numbering
-inline void KdHost::splice(const Sub& s, uint32_t node_off, uint32_t leaf_off) {
+inline void KdHost::splice(const Sub& s, uint32_t node_off, uint32_t pos_off) {
     if (s.c1) {
         const uint32_t o1 = node_off + 1, o2 = o1 + s.c1->total_nodes;
-        const uint32_t l2 = leaf_off + s.c1->total_leaves;
+        const uint32_t p2 = pos_off + s.c1->total_pos;
         KdNodeH nd = s.nodes[0];
-        nd.ref1 |= shift_ref(s.c1->root, o1, leaf_off);
-        nd.ref2 = shift_ref(s.c2->root, o2, l2);
+        nd.ref1 |= shift_ref(s.c1->root, o1, pos_off);
+        nd.ref2 = shift_ref(s.c2->root, o2, p2);
         nodes[node_off] = nd;
-        split[node_off] = 10u * l2;
-        splice(*s.c1, o1, leaf_off);
-        splice(*s.c2, o2, l2);
+        split[node_off] = p2;
+        splice(*s.c1, o1, pos_off);
+        splice(*s.c2, o2, p2);
         return;
     }
     for (size_t i = 0; i < s.nodes.size(); ++i) {
         KdNodeH nd = s.nodes[i];
-        nd.ref1 = shift_ref(nd.ref1, node_off, leaf_off);
-        nd.ref2 = shift_ref(nd.ref2, node_off, leaf_off);
+        nd.ref1 = shift_ref(nd.ref1, node_off, pos_off);
+        nd.ref2 = shift_ref(nd.ref2, node_off, pos_off);
         nodes[node_off + i] = nd;
-        split[node_off + i] = s.split[i] + 10u * leaf_off;
+        split[node_off + i] = s.split[i] + pos_off;
     }
-    for (size_t i = 0; i < s.pos_vert.size(); ++i) pos_vert[10 * (size_t)leaf_off + i] = s.pos_vert[i];
+    for (size_t i = 0; i < s.pos_vert.size(); ++i) pos_vert[(size_t)pos_off + i] = s.pos_vert[i];
 }
 
 inline void KdHost::build(const float* pts, uint32_t n, int threads) {
@@ -296,7 +317,8 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads) {
     nodes.clear();
     split.clear();
     pos_vert.clear();
-    n_leaves = 0;
+    if (group_max < 10) group_max = 10;
+    if (group_max > KD_GROUP_LIMIT) group_max = KD_GROUP_LIMIT;
     depth = 0;
     root_ref = KD_LEAF_BIT;
     for (int d = 0; d < 6; ++d) bbox[d] = 0;
@@ -319,16 +341,20 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads) {
     divide_par(top, 0, (int32_t)n, box, par_levels, (int32_t)(n / 64 + 1024));
     nodes.resize(top.total_nodes);
     split.resize(top.total_nodes);
-    pos_vert.assign(10 * (size_t)top.total_leaves, -1);
+    pos_vert.assign((size_t)top.total_pos, -1);
     splice(top, 0, 0);
-    n_leaves = top.total_leaves;
     depth = top.depth;
     root_ref = top.c1 ? 0u : top.root;
 }
 
 inline uint32_t KdHost::quad_of(uint32_t ref, int level) {
     ref &= ~(3u << KD_FEAT_SHIFT);
-    if (ref & KD_LEAF_BIT) return ref;
+    {   // a subtree of <= group_max vertices is one packet group (its block starts at a
+        // multiple of 4: the builder opened it at exactly this subtree)
+        uint32_t first, count;
+        subtree_extent(ref, first, count);
+        if (count <= group_max) return KD_LEAF_BIT | ((first >> 2) << 4) | ((count + 3u) >> 2);
+    }
     if (level + 1 > quad_depth) quad_depth = level + 1;
     const uint32_t self = (uint32_t)quads.size();
     quads.push_back({});
@@ -345,7 +371,9 @@ inline uint32_t KdHost::quad_of(uint32_t ref, int level) {
     uint32_t gref[4] = {0, 0, 0, 0};
     bool used[4] = {false, false, false, false};
     for (int side = 0; side < 2; ++side) {
-        if (child[side] & KD_LEAF_BIT) {
+        uint32_t cfirst, ccount;
+        subtree_extent(child[side], cfirst, ccount);
+        if (ccount <= group_max) {
             const int k = 2 * side;
             for (int d = 0; d < 3; ++d) q.box[k][d] = cbox[side][0][d], q.box[k][3 + d] = cbox[side][1][d];
             gref[k] = child[side];
@@ -369,6 +397,16 @@ inline uint32_t KdHost::quad_of(uint32_t ref, int level) {
 }
 
 inline void KdHost::build_quads() {
+    // extents of every binary subtree (children follow their parent in pre-order)
+    sub_first_.assign(nodes.size(), 0u);
+    sub_count_.assign(nodes.size(), 0u);
+    for (size_t i = nodes.size(); i-- > 0;) {
+        uint32_t f1, c1, f2, c2;
+        subtree_extent(nodes[i].ref1 & ~(3u << KD_FEAT_SHIFT), f1, c1);
+        subtree_extent(nodes[i].ref2, f2, c2);
+        sub_first_[i] = f1;
+        sub_count_[i] = c1 + c2;
+    }
     quads.clear();
     quads.reserve(nodes.size() / 2 + 8);
     quad_depth = 0;

@@ -550,12 +550,14 @@ constexpr int PBLOCK = SDFK_PBLOCK;
 
 
 // result of the packet pass for one lane
+constexpr uint32_t H_NONE = 0x7FFFFFFFu;
 struct PacketBest {
-    float b;  // global fp32 minimum over all vertices
-    float s;  // second smallest distance as a multiset (an exact tie shows as s == b); exact
-              // whenever it is <= b * c^2
-    int h;    // among the vertices at distance exactly b: the one nanoflann's near-first DFS
-              // (for THIS lane) meets first
+    float b;     // global fp32 minimum over all vertices
+    float s;     // second smallest distance as a multiset (an exact tie shows as s == b); exact
+                 // whenever it is <= b * c^2
+    uint32_t h;  // among the vertices at distance exactly b, the one nanoflann's near-first DFS
+                 // (for THIS lane) meets first: its tree position, or (bit 31) the ref of the
+                 // packet group in which it is the only vertex at that distance; H_NONE: none
 };
 
 // Which of two tree positions does nanoflann's DFS for query q meet first?  Walk down to the
@@ -580,35 +582,60 @@ __device__ __forceinline__ int kd_dfs_first(const MeshDev& M, float qx, float qy
     return pa < pb ? pa : pb;
 }
 
-// One slot of a leaf.  Distances are non-negative floats (or +inf / NaN), whose bit patterns
-// order like unsigned integers, so the multiset insert into (b, s2) and the strict-improvement
-// update of h run on the integer pipe without NaN canonicalisation.  Sentinel slots have
-// distance +inf and change nothing.
-#define SDFK_PACKET_SLOT(K)                                                        \
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// One slot of a group.  Distances are non-negative floats (or +inf / NaN), whose bit patterns
+// order like unsigned integers, so the multiset insert into (b <= s2) runs on the integer pipe
+// without NaN canonicalisation: new s2 = median(b, s2, d), new b = min(b, d).  Sentinel slots
+// have distance +inf and change nothing.  Which slot holds the minimum is not tracked here.
+#define SDFK_PACKET_SLOT(C_, O_)                                                   \
     {                                                                              \
-        const float4 P_ = P[K];                                                    \
-        const float dx_ = qx - P_.x, dy_ = qy - P_.y, dz_ = qz - P_.z;             \
+        const float dx_ = qx - __uint_as_float(C_[O_]);                            \
+        const float dy_ = qy - __uint_as_float(C_[O_ + 1]);                        \
+        const float dz_ = qz - __uint_as_float(C_[O_ + 2]);                        \
         const uint32_t du_ = __float_as_uint((dx_ * dx_ + dy_ * dy_) + dz_ * dz_); \
-        s2 = min(s2, max(du_, b));                                                 \
-        if (du_ < b) {                                                             \
-            b = du_;                                                               \
-            h = (int)(left + K);                                                   \
-        }                                                                          \
+        s2 = umed3(b, s2, du_);                                                    \
+        b = min(b, du_);                                                           \
     }
+#define SDFK_PACKET_CHUNK(C_) \
+    SDFK_PACKET_SLOT(C_, 0) SDFK_PACKET_SLOT(C_, 4) SDFK_PACKET_SLOT(C_, 8) SDFK_PACKET_SLOT(C_, 12)
+
+// One chunk = four padded vertices = 64 B = one s_load_dwordx16.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+
+// Deferred children of the wave live on a stack in LDS.  Per level: the uniform child ref and,
+// per lane, the upper 16 bits of that lane's box lower bound (truncation keeps it a lower
+// bound), so that a pop is one LDS read and a compare against the lane's current threshold —
+// no node reload, no box arithmetic.
+struct PacketStack {
+    uint16_t* lb;   // [level][64]
+    uint32_t* ref;  // [level]
+};
 
 __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float qx, float qy, float qz,
-                                                        uint32_t* stk) {
+                                                        const PacketStack stk) {
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t b = 0x7F7FFFFFu, s2 = 0x7F7FFFFFu;  // FLT_MAX bits (KNNResultSet::init)
-    int h = -1;
+    uint32_t h = H_NONE;
+    // A lane whose minimum is an exact tie that has been settled keeps s2 = b + 1 (so that one
+    // more vertex at that distance shows up again as s2 == b) and remembers the tied value here.
+    uint32_t tieb = 0xFFFFFFFFu;
     const float c = M.amb_c2;  // everything within best * c^2 is evaluated
     uint32_t cur = M.kd_qroot;
-    int sp = 0;
+    uint32_t sp = 0;
     for (;;) {
         cur = __builtin_amdgcn_readfirstlane(cur);
         bool need_pop = false;
         if (!(cur & KD_LEAF)) {
-            // 4-wide node: 32 dwords by scalar load; slots 0,1 / 2,3 are the two binary sides
+            // 4-wide node: boxes and child refs by scalar loads; slots 0,1 / 2,3 are the two
+            // binary sides
             const float* Q = (const float*)(M.kd_qn + 8 * (size_t)cur);
+            const uint32_t r0 = __float_as_uint(Q[24]), r1 = __float_as_uint(Q[25]),
+                           r2 = __float_as_uint(Q[26]), r3 = __float_as_uint(Q[27]);
             const float thr = __uint_as_float(b) * c;
             const float lb0 = box_lb(qx, qy, qz, Q[0], Q[1], Q[2], Q[3], Q[4], Q[5]);
             const float lb1 = box_lb(qx, qy, qz, Q[6], Q[7], Q[8], Q[9], Q[10], Q[11]);
@@ -620,84 +647,126 @@ __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float 
                                  (__ballot(lb3 <= thr) != 0ull ? 8u : 0u);
             if (act == 0u) {
                 need_pop = true;
+            } else if ((act & (act - 1u)) == 0u) {
+                cur = act == 1u ? r0 : (act == 2u ? r1 : (act == 4u ? r2 : r3));
             } else {
                 // visiting order by box distance, majority vote per comparison (any order is
-                // exact; nearer first tightens `b` sooner)
-                uint32_t seq;  // four 2-bit slot ids, nearest in the low bits
-                if ((act & (act - 1u)) == 0u) {
-                    seq = (uint32_t)__builtin_ctz(act) * 0x55u;  // single active slot
+                // exact; nearer first tightens `b` sooner).  Every active child is pushed,
+                // farthest first, then the nearest is taken straight back.
+                const uint32_t u0 = __float_as_uint(lb0), u1 = __float_as_uint(lb1),
+                               u2 = __float_as_uint(lb2), u3 = __float_as_uint(lb3);
+                const bool a_first = (int)__popcll(__ballot(min(u0, u1) <= min(u2, u3))) >= 32;
+                const bool s01 = (int)__popcll(__ballot(u0 <= u1)) >= 32;
+                const bool s23 = (int)__popcll(__ballot(u2 <= u3)) >= 32;
+                uint32_t last = 0;
+#define SDFK_PK_PUSH(K)                                              \
+    if (act & (1u << K)) {                                           \
+        stk.lb[sp * 64u + lane] = (uint16_t)(u##K >> 16);            \
+        stk.ref[sp] = r##K;                                          \
+        last = r##K;                                                 \
+        ++sp;                                                        \
+    }
+#define SDFK_PK_ORDER(A, B, C, D) { SDFK_PK_PUSH(D) SDFK_PK_PUSH(C) SDFK_PK_PUSH(B) SDFK_PK_PUSH(A) }
+                if (a_first) {
+                    if (s01) {
+                        if (s23) SDFK_PK_ORDER(0, 1, 2, 3) else SDFK_PK_ORDER(0, 1, 3, 2)
+                    } else {
+                        if (s23) SDFK_PK_ORDER(1, 0, 2, 3) else SDFK_PK_ORDER(1, 0, 3, 2)
+                    }
                 } else {
-                    const bool a_first = __popcll(__ballot(fminf(lb0, lb1) <= fminf(lb2, lb3))) >= 32;
-                    const bool s01 = __popcll(__ballot(lb0 <= lb1)) >= 32;
-                    const bool s23 = __popcll(__ballot(lb2 <= lb3)) >= 32;
-                    const uint32_t pa = s01 ? (0u | 1u << 2) : (1u | 0u << 2);
-                    const uint32_t pb = s23 ? (2u | 3u << 2) : (3u | 2u << 2);
-                    seq = a_first ? (pa | pb << 4) : (pb | pa << 4);
-                }
-                int pend = -1;
-#pragma unroll
-                for (int k = 3; k >= 0; --k) {
-                    const uint32_t sl = (seq >> (2 * k)) & 3u;
-                    if ((act >> sl) & 1u) {
-                        if (pend >= 0 && (uint32_t)pend != sl) stk[sp++] = (cur << 2) | (uint32_t)pend;
-                        pend = (int)sl;
+                    if (s01) {
+                        if (s23) SDFK_PK_ORDER(2, 3, 0, 1) else SDFK_PK_ORDER(3, 2, 0, 1)
+                    } else {
+                        if (s23) SDFK_PK_ORDER(2, 3, 1, 0) else SDFK_PK_ORDER(3, 2, 1, 0)
                     }
                 }
-                cur = __float_as_uint(Q[24 + pend]);
+#undef SDFK_PK_ORDER
+#undef SDFK_PK_PUSH
+                --sp;
+                cur = last;
             }
         } else {
-            const uint32_t left = (cur & sdfk::KD_REF_MASK) >> 4, cnt = cur & 15u;
-            const float4* P = M.kd_pts4 + left;  // uniform: scalar loads; ten slots always exist
-            const uint32_t b0 = b, s0 = s2;
-            const int h0 = h;
-            SDFK_PACKET_SLOT(0)
-            SDFK_PACKET_SLOT(1)
-            SDFK_PACKET_SLOT(2)
-            SDFK_PACKET_SLOT(3)
-            SDFK_PACKET_SLOT(4)
-            if (cnt > 5u) {
-                SDFK_PACKET_SLOT(5)
-                SDFK_PACKET_SLOT(6)
-                SDFK_PACKET_SLOT(7)
-                SDFK_PACKET_SLOT(8)
-                SDFK_PACKET_SLOT(9)
-            }
-            if (__ballot(s2 == b) != 0ull) {
-                // rare: some lane is in a tied state (second smallest == smallest; b is never
-                // FLT_MAX here once a vertex was seen).  Redo the leaf for the wave in
-                // nanoflann's order and settle each exact tie by DFS order.
-                b = b0, s2 = s0, h = h0;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    const float4 Qp = P[k];
-                    const float dx = qx - Qp.x, dy = qy - Qp.y, dz = qz - Qp.z;
-                    const uint32_t du = __float_as_uint((dx * dx + dy * dy) + dz * dz);
-                    const int idx = (int)(left + k);
-                    if (du == b && h >= 0 && !(h >= (int)left && h < idx))  // holder in another leaf
-                        h = kd_dfs_first(M, qx, qy, qz, h, idx);
-                    s2 = min(s2, max(du, b));
-                    if (du < b) {
-                        b = du;
-                        h = idx;
+            // packet group: chunks of four slots, 64 B each by scalar load; the next chunk is
+            // requested before the current one is evaluated (the slack behind the last block
+            // of the array covers the one-chunk overrun)
+            const uint32_t nch = cur & 15u;
+            const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
+            const float4* P = M.kd_pts4 + first;
+            const uint32_t b0 = b, s0 = s2, h0 = h;
+            if (nch) {
+                // the next chunk is requested before the current one is evaluated (its value
+                // is carried around the loop, so the load cannot sink to its use); the slack
+                // behind the array covers the one-chunk overrun of the last round
+                const u32x16* C = (const u32x16*)__builtin_assume_aligned(P, 64);
+                u32x16 A = C[0];
+#pragma unroll 2
+                for (uint32_t ci = 1;; ++ci) {
+                    const u32x16 B = C[ci];
+                    SDFK_PACKET_CHUNK(A)
+                    if (ci >= nch) break;
+                    A = B;
+                }
+                if (b != b0) h = cur;  // strictly improved here: the holder is in this group
+                if (__ballot(s2 == b) != 0ull) {
+                    // rare: some lane's two smallest distances are equal.  Redo the group for
+                    // the wave in ascending position and settle each exact tie by DFS order.
+                    b = b0, s2 = s0, h = h0;
+                    for (uint32_t k = 0; k < 4u * nch; ++k) {
+                        const float4 Qp = P[k];
+                        const float dx = qx - Qp.x, dy = qy - Qp.y, dz = qz - Qp.z;
+                        const uint32_t du = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+                        const uint32_t idx = first + k;
+                        if (du == b && h != H_NONE) {
+                            // any position of the holder's group stands for the holder: the
+                            // two part above that group
+                            const uint32_t hp = (h & KD_LEAF) ? (((h & sdfk::KD_REF_MASK) >> 4) << 2) : h;
+                            // (a group ref in h always names an earlier group: h0 predates this one)
+                            if ((uint32_t)kd_dfs_first(M, qx, qy, qz, (int)hp, (int)idx) == idx) h = idx;
+                        }
+                        s2 = min(s2, max(du, b));
+                        if (du < b) {
+                            b = du;
+                            h = idx;
+                        }
                     }
+                    if (s2 == b) tieb = b, s2 = b + 1u;
                 }
             }
             need_pop = true;
         }
         if (need_pop) {
+            const uint32_t thr16 = __float_as_uint(__uint_as_float(b) * c) >> 16;
             for (;;) {
-                if (sp == 0) return PacketBest{__uint_as_float(b), __uint_as_float(s2), h};
-                const uint32_t e = __builtin_amdgcn_readfirstlane(stk[--sp]);
-                const uint32_t parent = e >> 2, sl = e & 3u;
-                const float* Q = (const float*)(M.kd_qn + 8 * (size_t)parent);
-                const float* bx = Q + 6 * sl;
-                const float lb = box_lb(qx, qy, qz, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]);
-                if (__ballot(lb <= __uint_as_float(b) * c) != 0ull) {
-                    cur = __float_as_uint(Q[24 + sl]);
+                if (sp == 0) {
+                    if (b == tieb) s2 = b;
+                    return PacketBest{__uint_as_float(b), __uint_as_float(s2), h};
+                }
+                --sp;
+                const uint32_t l16 = stk.lb[sp * 64u + lane];
+                const uint32_t r = stk.ref[sp];
+                if (__ballot(l16 <= thr16) != 0ull) {
+                    cur = r;
                     break;
                 }
             }
         }
     }
+}
+
+// The exact tree position behind PacketBest::h: a group ref is resolved by finding the group's
+// one vertex at distance b (per lane, once per query).
+__device__ __forceinline__ int packet_resolve(const MeshDev& M, float qx, float qy, float qz, float bf,
+                                              uint32_t h) {
+    if (h == H_NONE) return -1;
+    if (!(h & KD_LEAF)) return (int)h;
+    const uint32_t first = ((h & sdfk::KD_REF_MASK) >> 4) << 2, n = 4u * (h & 15u);
+    const uint32_t b = __float_as_uint(bf);
+    for (uint32_t k = 0; k < n; ++k) {
+        const float4 P = M.kd_pts4[first + k];
+        const float dx = qx - P.x, dy = qy - P.y, dz = qz - P.z;
+        if (__float_as_uint((dx * dx + dy * dy) + dz * dz) == b) return (int)(first + k);
+    }
+    return -1;
 }
 
 // Largest mindistsq' that nanoflann tests on its way to the leaf holding tree position `pos`
@@ -747,7 +816,10 @@ __global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float*
                                                          uint32_t* __restrict__ amb_cnt,
                                                          uint32_t depth_cap) {
     extern __shared__ uint32_t lds[];
-    uint32_t* stk = lds + (threadIdx.x >> 6) * depth_cap;
+    // per wave: depth_cap rows of 64 x u16 lower bounds, then depth_cap refs
+    PacketStack stk;
+    stk.lb = (uint16_t*)(lds + (threadIdx.x >> 6) * depth_cap * 33u);
+    stk.ref = lds + (threadIdx.x >> 6) * depth_cap * 33u + depth_cap * 32u;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     // lanes past the end of the batch repeat its last query (and write nothing): they then ask
@@ -768,16 +840,16 @@ __global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float*
     //  (2) otherwise measure it: every bound tested on the way to pb.h is <= the distance of
     //      any other vertex (>= pb.s; == b for an exact tie, where pb.h is the first met);
     //  (3) else defer to the strict kernel (exact emulation).
-    const int pos = pb.h;
+    const int pos = packet_resolve(M, p.x, p.y, p.z, pb.b, pb.h);
     bool amb = false;
     if (valid && (!(pb.s > pb.b * M.amb_c) || !(pb.b >= 1e-30f))) {
         amb = true;
-        if (pb.h >= 0 && pb.b < FLT_MAX) {
-            const float mb = kd_path_max_bound(M, p.x, p.y, p.z, pb.h);
+        if (pos >= 0 && pb.b < FLT_MAX) {
+            const float mb = kd_path_max_bound(M, p.x, p.y, p.z, pos);
             amb = !(mb <= pb.s);
         }
     }
-    if (pb.h < 0) amb = true;
+    if (pos < 0) amb = true;
     {   // ambiguous lanes of this wave, in sorted order: compacted (stably) by k_fb_compact so
         // that the strict fallback kernel still sees Morton-coherent waves
         const unsigned long long m = __ballot(valid && amb);
@@ -1522,7 +1594,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     }
     // vertices in (padded) tree order; sentinel slots are far away: their distance is +inf
     const size_t npos = h->kd.pos_vert.size();
-    const size_t nalloc = npos + 16;  // a leaf is always read as ten slots
+    const size_t nalloc = npos + 16;  // the packet pass reads one chunk (4 slots) past a group
     if (nalloc > h->kd_pos_cap) {
         if (int rc = dalloc(&h->d_kd_pts, 3 * nalloc)) return rc;
         if (int rc = dalloc(&h->d_kd_pts4, nalloc)) return rc;
@@ -1673,9 +1745,10 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     const MeshDev M = mesh_view(h);
     const size_t osz = KIND == Q_CONTAINS ? 1 : (KIND == Q_DETAIL ? 12 : 4);
     const int64_t chunk = h->opt_chunk > 0 ? h->opt_chunk : (1 << 24);
-    const uint32_t depth = (uint32_t)(h->kd.depth > 0 ? h->kd.depth : 1);
     const bool sort_any = h->opt_sort && n >= h->opt_sort_min;
-    const bool packet_any = sort_any && KIND != Q_DETAIL && h->opt_packet && depth < 4096;
+    // packet stack: <= 3 deferred slots per 4-wide level (+ the transient 4th); 132 B per slot
+    const uint32_t pstack = 3u * (uint32_t)(h->kd.quad_depth > 0 ? h->kd.quad_depth : 1) + 4u;
+    const bool packet_any = sort_any && KIND != Q_DETAIL && h->opt_packet && pstack * 132u <= 48u * 1024u;
     const int64_t fb_cap = packet_any ? (n < (1ll << 27) ? n : (1ll << 27)) : 0;
     if (sort_any)
         if (int rc = reserve_query_ws(h, n < chunk ? n : chunk, fb_cap)) return rc;
@@ -1714,9 +1787,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         if (perm && packet_any) {
             if (deferred_pts + m > h->fb_cap)
                 if (int rc = flush()) return rc;
-            // packet stack: <= 3 deferred slots per 4-wide level
-            const uint32_t pstack = 3u * (uint32_t)(h->kd.quad_depth > 0 ? h->kd.quad_depth : 1) + 4u;
-            const size_t lds = (size_t)(PBLOCK / 64) * pstack * sizeof(uint32_t);
+            const size_t lds = (size_t)(PBLOCK / 64) * pstack * 33u * sizeof(uint32_t);
             constexpr int PK = KIND == Q_DETAIL ? Q_NN : KIND;
             ProfScope prof{h, s};  // the dominant kernel, one event pair per launch
             if (int rc = prof.begin()) return rc;
@@ -2129,7 +2200,12 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_build_threads = v < 1 ? 1 : v;
     else if (!strcmp(key, "packet"))
         h->opt_packet = v;
-    else if (!strcmp(key, "sort_min"))
+    else if (!strcmp(key, "packet_group")) {
+        // vertices per packet group; takes effect at the next sdfhip_update
+        if (v < 10 || v > (int64_t)sdfk::KD_GROUP_LIMIT)
+            return fail(SDFHIP_E_INVALID, "packet_group must be in [10, %u]", sdfk::KD_GROUP_LIMIT);
+        h->kd.group_max = (uint32_t)v;
+    } else if (!strcmp(key, "sort_min"))
         h->opt_sort_min = v;
     else if (!strcmp(key, "chunk")) {
         if (v < 1024 || v > (1ll << 27)) return fail(SDFHIP_E_INVALID, "chunk must be in [1024, 2^27]");

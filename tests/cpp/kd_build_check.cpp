@@ -1,9 +1,50 @@
-// The task-parallel kd build must produce byte-identical arrays to the serial build.
+// The task-parallel kd build must produce byte-identical arrays to the serial build, and the
+// packet groups of the 4-wide tree must tile the padded position space exactly.
 #include <cstdio>
 #include <cstring>
 #include <random>
 #include <vector>
 #include "../../sdf_amd/csrc/kd_host.h"
+
+static bool groups_ok(const sdfk::KdHost& k, int n) {
+    std::vector<int> seen(k.pos_vert.size(), 0);
+    std::vector<int> vseen(n, 0);
+    auto mark = [&](uint32_t ref) {
+        const uint32_t first = ((ref & sdfk::KD_REF_MASK) >> 4) << 2, chunks = ref & 15u;
+        if (first + 4 * chunks > k.pos_vert.size()) return false;
+        for (uint32_t i = first; i < first + 4 * chunks; ++i) seen[i]++;
+        return true;
+    };
+    if (k.quad_root & sdfk::KD_LEAF_BIT) {
+        if (!mark(k.quad_root)) return false;
+    }
+    for (const auto& q : k.quads)
+        for (int s = 0; s < 4; ++s) {
+            const bool used = q.box[s][0] <= q.box[s][3];
+            if (!used) continue;
+            if (q.ref[s] & sdfk::KD_LEAF_BIT) {
+                if (!mark(q.ref[s])) return false;
+                // every vertex of the group lies in the slot's box
+                const uint32_t first = ((q.ref[s] & sdfk::KD_REF_MASK) >> 4) << 2, chunks = q.ref[s] & 15u;
+                int real = 0;
+                for (uint32_t i = first; i < first + 4 * chunks; ++i) real += k.pos_vert[i] >= 0;
+                // (an empty leaf, which nanoflann can produce on degenerate splits, is an empty group)
+                if ((real == 0) != (chunks == 0) || real > (int)k.group_max) return false;
+            } else if (q.ref[s] >= k.quads.size()) {
+                return false;
+            }
+        }
+    for (size_t i = 0; i < seen.size(); ++i)
+        if (seen[i] != 1) return false;
+    for (int32_t v : k.pos_vert)
+        if (v >= 0) {
+            if (v >= n || vseen[v]++) return false;
+        }
+    for (int i = 0; i < n; ++i)
+        if (!vseen[i]) return false;
+    return k.pos_vert.size() % 4 == 0;
+}
+
 int main() {
     std::mt19937 rg(5);
     std::uniform_real_distribution<float> U(-1, 1);
@@ -11,15 +52,22 @@ int main() {
         for (int mode = 0; mode < 2; ++mode) {
             std::vector<float> p(3 * (size_t)n);
             for (auto& x : p) x = mode ? (float)(int)(U(rg) * 6) * 0.25f : U(rg);  // lattice: many equal keys
-            sdfk::KdHost a, b;
-            a.build(p.data(), n, 1);
-            b.build(p.data(), n, 8);
-            bool ok = a.root_ref == b.root_ref && a.depth == b.depth && a.n_leaves == b.n_leaves &&
-                      a.vind == b.vind && a.pos_vert == b.pos_vert && a.split == b.split &&
-                      a.nodes.size() == b.nodes.size() &&
-                      !memcmp(a.nodes.data(), b.nodes.data(), a.nodes.size() * sizeof(sdfk::KdNodeH)) &&
-                      !memcmp(a.bbox, b.bbox, sizeof(a.bbox));
-            if (!ok) { printf("MISMATCH n=%d mode=%d\n", n, mode); return 1; }
+            for (uint32_t g : {10u, 16u, 32u, 60u}) {
+                sdfk::KdHost a, b;
+                a.group_max = b.group_max = g;
+                a.build(p.data(), n, 1);
+                b.build(p.data(), n, 8);
+                a.build_quads();
+                b.build_quads();
+                bool ok = a.root_ref == b.root_ref && a.depth == b.depth && a.vind == b.vind &&
+                          a.pos_vert == b.pos_vert && a.split == b.split && a.nodes.size() == b.nodes.size() &&
+                          !memcmp(a.nodes.data(), b.nodes.data(), a.nodes.size() * sizeof(sdfk::KdNodeH)) &&
+                          !memcmp(a.bbox, b.bbox, sizeof(a.bbox)) && a.quad_root == b.quad_root &&
+                          a.quads.size() == b.quads.size() &&
+                          !memcmp(a.quads.data(), b.quads.data(), a.quads.size() * sizeof(sdfk::KdQuadH));
+                if (!ok) { printf("MISMATCH n=%d mode=%d g=%u\n", n, mode, g); return 1; }
+                if (!groups_ok(a, n)) { printf("BAD GROUPS n=%d mode=%d g=%u\n", n, mode, g); return 1; }
+            }
         }
     }
     printf("ok\n");

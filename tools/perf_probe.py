@@ -13,9 +13,13 @@ ap.add_argument("--grid", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--robust", type=int, default=1)
 ap.add_argument("--only", default="")
+ap.add_argument("--group", type=int, default=0, help="packet_group option (0 = library default)")
 a = ap.parse_args()
 v, f = meshes.torus(a.res, a.res)
 s = sdf_amd.SDF(v, f, robust=bool(a.robust))
+if a.group:
+    s.set_option("packet_group", a.group)
+    s.update()
 s.set_raycast_axes(meshes.random_rotation(1234))
 dev = torch.device("cuda", 0)
 if a.grid:
