@@ -69,7 +69,7 @@ constexpr uint32_t KD_GROUP_LIMIT = 60;        // chunks of a group fit 4 bits
 struct KdHost {
     std::vector<int32_t> vind;      // nanoflann's permutation (dense, size n)
     std::vector<int32_t> pos_vert;  // padded tree position -> vertex index, -1 = sentinel slot
-    uint32_t group_max = 16;        // vertices per packet group (10 = one group per leaf)
+    uint32_t group_max = 24;        // vertices per packet group (10 = one group per leaf)
     std::vector<KdNodeH> nodes;
     std::vector<uint32_t> split;  // parallel to nodes
     uint32_t root_ref = KD_LEAF_BIT;  // empty leaf
