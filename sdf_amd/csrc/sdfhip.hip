@@ -686,25 +686,16 @@ __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float 
                 cur = last;
             }
         } else {
-            // packet group: chunks of four slots, 64 B each by scalar load; the next chunk is
-            // requested before the current one is evaluated (the slack behind the last block
-            // of the array covers the one-chunk overrun)
+            // packet group: chunks of four slots, 64 B each by one scalar load
             const uint32_t nch = cur & 15u;
             const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
             const float4* P = M.kd_pts4 + first;
             const uint32_t b0 = b, s0 = s2, h0 = h;
             if (nch) {
-                // the next chunk is requested before the current one is evaluated (its value
-                // is carried around the loop, so the load cannot sink to its use); the slack
-                // behind the array covers the one-chunk overrun of the last round
                 const u32x16* C = (const u32x16*)__builtin_assume_aligned(P, 64);
-                u32x16 A = C[0];
-#pragma unroll 2
-                for (uint32_t ci = 1;; ++ci) {
-                    const u32x16 B = C[ci];
+                for (uint32_t ci = 0; ci < nch; ++ci) {
+                    const u32x16 A = C[ci];
                     SDFK_PACKET_CHUNK(A)
-                    if (ci >= nch) break;
-                    A = B;
                 }
                 if (b != b0) h = cur;  // strictly improved here: the holder is in this group
                 if (__ballot(s2 == b) != 0ull) {
@@ -1175,14 +1166,31 @@ struct Bounds {
     float lo[3], inv[3];
 };
 
-__global__ void k_face_morton(const float4* __restrict__ geo, uint32_t nf, Bounds B,
+__device__ __forceinline__ uint32_t expand16(uint32_t v) {  // 16 bits -> every other bit
+    v &= 0xFFFFu;
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+// Faces are ordered by the 2-D Morton code of their centroid in the (x', y') plane of the
+// ray-cast frame: the parity rays are columns along z', so faces that one column can meet —
+// whatever their z' — are neighbours in this order and share low subtrees.  (The x+ tie-break
+// ray walks the same tree less efficiently; it is cast only when z+ and z- disagree.)
+__global__ void k_face_morton(const float4* __restrict__ geo, uint32_t nf, Bounds B, RMat R,
                               uint32_t* __restrict__ keys) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nf) return;
     const float4 g0 = geo[4 * (size_t)f], g1 = geo[4 * (size_t)f + 1], g2 = geo[4 * (size_t)f + 2];
     const float cx = (g0.x + g0.w + g1.z) * (1.f / 3.f), cy = (g0.y + g1.x + g1.w) * (1.f / 3.f),
                 cz = (g0.z + g1.y + g2.x) * (1.f / 3.f);
-    keys[f] = morton30(cx, cy, cz, B.lo, B.inv);
+    const float rx = cx * R.m[0] + cy * R.m[3] + cz * R.m[6];
+    const float ry = cx * R.m[1] + cy * R.m[4] + cz * R.m[7];
+    float fx = (rx - B.lo[0]) * B.inv[0], fy = (ry - B.lo[1]) * B.inv[1];
+    fx = fminf(fmaxf(fx, 0.f), 65535.f);
+    fy = fminf(fmaxf(fy, 0.f), 65535.f);
+    keys[f] = (expand16((uint32_t)fx) << 1) | expand16((uint32_t)fy);
 }
 
 // query chunk bounds: block min/max -> atomics on an order-preserving uint encoding
@@ -1438,6 +1446,7 @@ struct sdfhip_ctx {
     LbvhTopo topo{};
     uint32_t bvh_depth = 0;
     bool topo_built = false;
+    float topo_R[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // rotation the LBVH topology was built for
     RadixSorter sorter;
     // query workspace
     uint32_t* d_qkeys = nullptr;
@@ -1511,13 +1520,26 @@ int build_topology(sdfhip_ctx* h) {
         h->topo_built = true;
         return 0;
     }
+    // range of x', y' over the mesh: from the rotated corners of the world AABB
     Bounds B;
-    for (int d = 0; d < 3; ++d) {
-        B.lo[d] = h->aabb[d];
-        const float ext = h->aabb[d + 3] - h->aabb[d];
-        B.inv[d] = ext > 0.f ? 1024.f / ext : 0.f;
+    RMat R;
+    std::memcpy(R.m, h->R, sizeof(R.m));
+    float lo[2] = {FLT_MAX, FLT_MAX}, hi[2] = {-FLT_MAX, -FLT_MAX};
+    for (int c = 0; c < 8; ++c) {
+        const float x = h->aabb[(c & 1) ? 3 : 0], y = h->aabb[(c & 2) ? 4 : 1], z = h->aabb[(c & 4) ? 5 : 2];
+        for (int d = 0; d < 2; ++d) {
+            const float r = x * R.m[d] + y * R.m[3 + d] + z * R.m[6 + d];
+            lo[d] = r < lo[d] ? r : lo[d];
+            hi[d] = r > hi[d] ? r : hi[d];
+        }
     }
-    k_face_morton<<<(n + 255) / 256, 256, 0, s>>>(h->d_geo, n, B, h->d_codes);
+    for (int d = 0; d < 2; ++d) {
+        B.lo[d] = lo[d];
+        const float ext = hi[d] - lo[d];
+        B.inv[d] = ext > 0.f && ext < FLT_MAX ? 65536.f / ext : 0.f;
+    }
+    B.lo[2] = 0.f, B.inv[2] = 0.f;
+    k_face_morton<<<(n + 255) / 256, 256, 0, s>>>(h->d_geo, n, B, R, h->d_codes);
     if (int rc = h->sorter.sort(h->d_codes, h->d_sorted_face, n, 32, 1, s, nullptr, nullptr)) return rc;
     HIPC(hipMemsetAsync(h->d_maxdepth, 0, sizeof(uint32_t), s));
     if (n > 1) k_lbvh_karras<<<(n - 1 + 255) / 256, 256, 0, s>>>(h->d_codes, (int)n, h->topo);
@@ -1527,6 +1549,7 @@ int build_topology(sdfhip_ctx* h) {
     HIPC(hipStreamSynchronize(s));
     h->n_rnodes = 2 * n - 1;
     h->topo_built = true;
+    std::memcpy(h->topo_R, h->R, sizeof(h->topo_R));
     return 0;
 }
 
@@ -1555,7 +1578,8 @@ int update_device_side(sdfhip_ctx* h) {
     HIPC(hipGetLastError());
     h->h_face_valid = false;
     if (h->robust) {
-        if (!h->topo_built)
+        // the face order follows the ray-cast frame: rebuilt when R changed, refit otherwise
+        if (!h->topo_built || std::memcmp(h->topo_R, h->R, sizeof(h->topo_R)) != 0)
             if (int rc = build_topology(h)) return rc;
         if (int rc = refit(h)) return rc;
     }

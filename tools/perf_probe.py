@@ -36,6 +36,7 @@ for name, fn in (("nn", s.nn), ("contains", s.contains), ("sdf", s.__call__)):
         continue
     fn(pts); torch.cuda.synchronize()
     best = 1e9
+    s.set_option("profile", 2)
     for _ in range(a.reps):
         t0 = time.perf_counter(); fn(pts); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-    print(f"{name:9s} {best*1e3:9.2f} ms  {n/best/1e6:9.1f} Mevals/s  fallback {s.stats['last_fallback_points']}", flush=True)
+    print(f"{name:9s} {best*1e3:9.2f} ms  {n/best/1e6:9.1f} Mevals/s  fallback {s.stats['last_fallback_points']}  kernel {s.stats['query_kernel_ms']/max(1,s.stats['query_kernel_launches']):.2f} ms", flush=True)
