@@ -25,7 +25,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <random>
 #include <string>
 #include <vector>
@@ -1454,12 +1456,17 @@ struct sdfhip_ctx {
     uint32_t* d_qbounds = nullptr;
     uint32_t* d_gstack = nullptr;
     size_t gstack_words = 0;
-    float* d_stage_pts = nullptr;
-    void* d_stage_out = nullptr;
     int64_t q_cap = 0;
     // options
     int64_t opt_sort = 1, opt_sort_min = 8192, opt_chunk = 1 << 27;
     hipStream_t stream = nullptr;  // internal stream for create/update and host entry points
+    // host entry points: double-buffered device staging, copies on their own streams
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    float* d_stage_in[2] = {nullptr, nullptr};
+    void* d_stage_out[2] = {nullptr, nullptr};
+    int64_t stage_cap = 0;     // points per staging slot
+    int64_t opt_host_chunk = 0;  // 0 = automatic
     std::mutex mu;
     std::mt19937 rng;
     float last_update_ms = 0.f, last_kd_ms = 0.f;
@@ -1864,7 +1871,35 @@ int run_query(sdfhip_ctx* h, int kind, const float* d_pts, int64_t n, int trunc,
     return fail(SDFHIP_E_INVALID, "unknown query kind");
 }
 
-// host-pointer entry: stage through device buffers in chunks
+// host-pointer entry: the batch is cut into chunks that flow through two device staging slots,
+//   H2D(c+1) on s_in  ||  query(c) on the handle's stream  ||  D2H(c-1) on s_out,
+// so that the PCIe transfers of pageable caller memory (blocking for the host, asynchronous
+// for the GPU) overlap the kernels.  Chunks stay large (>= n/4, up to 2^25 points): the packet
+// pass is faster on dense Morton-sorted batches.
+int ensure_host_staging(sdfhip_ctx* h, int64_t cap) {
+    if (!h->s_in) HIPC(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+    if (!h->s_out) HIPC(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        if (!h->ev_in[k]) HIPC(hipEventCreateWithFlags(&h->ev_in[k], hipEventDisableTiming));
+        if (!h->ev_done[k]) HIPC(hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming));
+    }
+    if (cap <= h->stage_cap) return 0;
+    for (int k = 0; k < 2; ++k) {
+        if (h->d_stage_in[k]) (void)hipFree(h->d_stage_in[k]);
+        if (h->d_stage_out[k]) (void)hipFree(h->d_stage_out[k]);
+        h->d_stage_in[k] = nullptr, h->d_stage_out[k] = nullptr;
+    }
+    h->stage_cap = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (hipMalloc((void**)&h->d_stage_in[k], sizeof(float) * 3 * (size_t)cap) != hipSuccess ||
+            hipMalloc(&h->d_stage_out[k], 12 * (size_t)cap) != hipSuccess)
+            return fail(SDFHIP_E_NOMEM, "hipMalloc failed for the host staging buffers (%lld points)",
+                        (long long)cap);
+    }
+    h->stage_cap = cap;
+    return 0;
+}
+
 int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int trunc, void* out) {
     if (!h) return fail(SDFHIP_E_INVALID, "null handle");
     if (n < 0) return fail(SDFHIP_E_INVALID, "negative point count");
@@ -1874,31 +1909,92 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
     DevGuard g(h->device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
     const size_t osz = kind == Q_CONTAINS ? 1 : (kind == Q_DETAIL ? 12 : 4);
-    const int64_t chunk = 1 << 26;  // device staging batch: large batches keep the Morton-sorted waves compact
-    const int64_t cap = n < chunk ? n : chunk;
-    float* d_p = nullptr;
-    void* d_o = nullptr;
-    HIPC(hipMalloc((void**)&d_p, sizeof(float) * 3 * (size_t)cap));
-    if (hipMalloc(&d_o, osz * (size_t)cap) != hipSuccess) {
-        (void)hipFree(d_p);
-        return fail(SDFHIP_E_NOMEM, "hipMalloc failed for the output staging buffer");
+    int64_t cap = h->opt_host_chunk;
+    if (cap <= 0) {
+        cap = (n + 3) / 4;
+        if (cap < (1 << 21)) cap = 1 << 21;
+        if (cap > (1 << 25)) cap = 1 << 25;
     }
+    if (cap > n) cap = n;
+    if (int rc = ensure_host_staging(h, cap)) return rc;
+    const int64_t nchunks = (n + cap - 1) / cap;
+    auto span = [&](int64_t c) { return (n - c * cap) < cap ? (n - c * cap) : cap; };
     int rc = 0;
-    for (int64_t off = 0; off < n && !rc; off += cap) {
-        const int64_t m = (n - off) < cap ? (n - off) : cap;
-        hipError_t e = hipMemcpyAsync(d_p, pts + 3 * off, sizeof(float) * 3 * (size_t)m,
-                                      hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess) {
-            rc = run_query(h, kind, d_p, m, trunc, d_o, h->stream);
-            if (!rc)
-                e = hipMemcpyAsync((char*)out + osz * (size_t)off, d_o, osz * (size_t)m,
-                                   hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = hipSuccess;
+    auto upload = [&](int64_t c) {
+        const int k = (int)(c & 1);
+        e = hipMemcpyAsync(h->d_stage_in[k], pts + 3 * c * cap, sizeof(float) * 3 * (size_t)span(c),
+                           hipMemcpyHostToDevice, h->s_in);
+        if (e == hipSuccess) e = hipEventRecord(h->ev_in[k], h->s_in);
+    };
+    auto launch = [&](int64_t c) {
+        const int k = (int)(c & 1);
+        e = hipStreamWaitEvent(h->stream, h->ev_in[k], 0);
+        if (e != hipSuccess) return;
+        rc = run_query(h, kind, h->d_stage_in[k], span(c), trunc, h->d_stage_out[k], h->stream);
+        if (!rc) e = hipEventRecord(h->ev_done[k], h->stream);
+    };
+    // Downloads run on a helper thread: a D2H copy into pageable memory blocks its caller just
+    // like an H2D copy does, and the two directions are independent.
+    std::mutex mx;
+    std::condition_variable cv;
+    int64_t launched = 0, downloaded = 0;  // chunks whose query is enqueued / whose results are home
+    bool stop = false;
+    hipError_t e_dl = hipSuccess;
+    auto download_loop = [&]() {
+        if (hipSetDevice(h->device) != hipSuccess) {
+            std::lock_guard<std::mutex> l(mx);
+            e_dl = hipErrorInvalidDevice;
+            cv.notify_all();
+            return;
         }
-        if (!rc && e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (!rc && e != hipSuccess) rc = fail(SDFHIP_E_HIP, "HIP error in query: %s", hipGetErrorString(e));
+        for (int64_t c = 0; c < nchunks; ++c) {
+            {
+                std::unique_lock<std::mutex> l(mx);
+                cv.wait(l, [&] { return launched > c || stop; });
+                if (launched <= c) return;
+            }
+            const int k = (int)(c & 1);
+            hipError_t ed = hipStreamWaitEvent(h->s_out, h->ev_done[k], 0);
+            if (ed == hipSuccess)
+                ed = hipMemcpyAsync((char*)out + osz * (size_t)(c * cap), h->d_stage_out[k],
+                                    osz * (size_t)span(c), hipMemcpyDeviceToHost, h->s_out);
+            if (ed == hipSuccess) ed = hipStreamSynchronize(h->s_out);
+            std::lock_guard<std::mutex> l(mx);
+            if (ed != hipSuccess) e_dl = ed;
+            downloaded = c + 1;  // slot k is free again
+            cv.notify_all();
+            if (ed != hipSuccess) return;
+        }
+    };
+    std::thread dl(download_loop);
+    for (int64_t c = 0; c < nchunks && !rc && e == hipSuccess; ++c) {
+        {   // slot c & 1 was last used by chunk c - 2
+            std::unique_lock<std::mutex> l(mx);
+            cv.wait(l, [&] { return downloaded >= c - 1 || e_dl != hipSuccess; });
+            if (e_dl != hipSuccess) break;
+        }
+        upload(c);  // the host blocks here while earlier chunks run and download
+        if (e == hipSuccess) launch(c);
+        if (!rc && e == hipSuccess) {
+            std::lock_guard<std::mutex> l(mx);
+            launched = c + 1;
+            cv.notify_all();
+        }
     }
-    (void)hipFree(d_p);
-    (void)hipFree(d_o);
+    {
+        std::lock_guard<std::mutex> l(mx);
+        if (rc || e != hipSuccess) stop = true;
+        cv.notify_all();
+    }
+    dl.join();
+    if (!rc && e == hipSuccess && e_dl != hipSuccess) e = e_dl;
+    if (rc || e != hipSuccess) {
+        (void)hipStreamSynchronize(h->s_in);
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->s_out);
+        if (!rc) rc = fail(SDFHIP_E_HIP, "HIP error in query: %s", hipGetErrorString(e));
+    }
     return rc;
 }
 
@@ -2048,6 +2144,14 @@ void sdfhip_destroy(sdfhip_t* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->sorter.release();
+    for (int k = 0; k < 2; ++k) {
+        if (h->d_stage_in[k]) (void)hipFree(h->d_stage_in[k]);
+        if (h->d_stage_out[k]) (void)hipFree(h->d_stage_out[k]);
+        if (h->ev_in[k]) (void)hipEventDestroy(h->ev_in[k]);
+        if (h->ev_done[k]) (void)hipEventDestroy(h->ev_done[k]);
+    }
+    if (h->s_in) (void)hipStreamDestroy(h->s_in);
+    if (h->s_out) (void)hipStreamDestroy(h->s_out);
     for (auto& ev : h->prof_pending) (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
     for (auto& ev : h->prof_free) (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -2224,7 +2328,11 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_build_threads = v < 1 ? 1 : v;
     else if (!strcmp(key, "packet"))
         h->opt_packet = v;
-    else if (!strcmp(key, "packet_group")) {
+    else if (!strcmp(key, "host_chunk")) {
+        if (v != 0 && (v < 1024 || v > (1ll << 27)))
+            return fail(SDFHIP_E_INVALID, "host_chunk must be 0 (automatic) or in [1024, 2^27]");
+        h->opt_host_chunk = v;
+    } else if (!strcmp(key, "packet_group")) {
         // vertices per packet group; takes effect at the next sdfhip_update
         if (v < 10 || v > (int64_t)sdfk::KD_GROUP_LIMIT)
             return fail(SDFHIP_E_INVALID, "packet_group must be in [10, %u]", sdfk::KD_GROUP_LIMIT);
