@@ -23,6 +23,8 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <chrono>
+#include <random>
 #include <vector>
 
 #include "../sdfhip.h"
@@ -58,6 +60,11 @@ struct SDF {
         : SDF(verts.data(), (uint32_t)verts.rows(), faces.data(), (uint32_t)faces.rows(), robust, copy) {}
 #endif
     ~SDF() { sdfhip_destroy(h_); }
+    static uint64_t fresh_seed() {
+        std::random_device rd;
+        return ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^
+               (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+    }
     SDF(const SDF&) = delete;  // as the reference: const members + pImpl
     SDF& operator=(const SDF&) = delete;
 
@@ -111,6 +118,29 @@ struct SDF {
 #endif
     // sdf.hpp:206-208 / sdf.cpp:391
     void update() { check(sdfhip_update(h_)); }
+
+    // sdf.hpp:210-213 / sdf.cpp:176-234.  `seed` (extension) makes the samples reproducible;
+    // by default a fresh one is drawn, like the reference's time-seeded generator.
+    std::vector<float> sample_surface_vec(int num_points, uint64_t seed = fresh_seed()) const {
+        if (num_faces() == 0) {
+            std::cerr << "ERROR: No faces, can't sample surface.\n";  // sdf.cpp:178
+            return {};
+        }
+        std::vector<float> out(3 * (size_t)(num_points > 0 ? num_points : 0));
+        check(sdfhip_sample_surface(h_, num_points, seed, out.data()));
+        return out;
+    }
+#ifdef SDF_AMD_HAVE_EIGEN
+    Points sample_surface(int num_points) const {
+        if (num_faces() == 0) {
+            std::cerr << "ERROR: No faces, can't sample surface.\n";
+            return Points();
+        }
+        Points out(num_points, 3);
+        check(sdfhip_sample_surface(h_, num_points, fresh_seed(), out.data()));
+        return out;
+    }
+#endif
 
     // the reference's rotation is private and random (sdf.cpp:43-48); parity needs it injectable
     void set_raycast_axes(const float R[9], bool pin = true) { check(sdfhip_set_raycast_axes(h_, R, pin)); }

@@ -120,6 +120,16 @@ int sdfhip_aabb(const sdfhip_t* h, float out[6]);
  * Returns the count (>= 0) or a negative error; *ids points into handle-owned memory. */
 int sdfhip_adj_faces(const sdfhip_t* h, uint32_t vert, const int32_t** ids);
 
+/* Replaces SDF::sample_surface(num_points) (sdf.hpp:206-209, sdf.cpp:176-234): n points on the
+ * surface, float32 [n,3]; face i with probability face_areas[i] / surface_area through the
+ * running sum of face areas, then a uniform point of the parallelogram (a, b-a, c-a) reflected
+ * over bc.  The reference draws from a time-seeded mt19937 (util.cpp:32-40); here sample j uses
+ * Philox4x32-10(key = seed, counter = j), so equal seeds give equal samples and the
+ * distribution, not the values, is what matches the reference.  No faces: SDFHIP_E_STATE with
+ * the reference's message. */
+int sdfhip_sample_surface(sdfhip_t* h, int64_t n, uint64_t seed, float* out);
+int sdfhip_sample_surface_device(sdfhip_t* h, int64_t n, uint64_t seed, float* d_out, void* stream);
+
 /* Statistics of the structures behind the handle (no counterpart in the reference). */
 typedef struct {
     int32_t kd_nodes;      /* internal nodes of the vertex kd-tree */
@@ -140,6 +150,8 @@ int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* out);
 
 /* Tuning knobs (no counterpart). key: "sort_queries" (0/1, default 1: Morton-sort query
  * chunks of >= sort_min points), "sort_min", "chunk" (points per internal chunk), "packet" (0: strict kernel only),
+ * "packet_group" (vertices per leaf group of the packet pass, 10..60, applies at the next update), "host_chunk" (points per
+ * staging slot of the host entry points, 0 = automatic),
  * "build_threads" (host threads of the kd-tree build; default min(cores, OMP_NUM_THREADS, 16)), "profile" (1: time every query kernel launch
  * with hipEvents on its stream, read back through sdfhip_get_stats; 2: same and reset). */
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t value);

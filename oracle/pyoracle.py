@@ -66,6 +66,7 @@ def _load():
     L.orc_kd_export.argtypes = [C.c_void_p, _ip, _ip, _fp]
     L.orc_kd_stats.argtypes = [C.c_void_p, _fp, C.c_int, C.POINTER(C.c_double)]
     L.orc_quat_to_R.argtypes = [_fp, _fp]
+    L.orc_sample_surface.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_float, _fp]
     L.orc_dist_point2tri.restype = C.c_float
     L.orc_dist_point2tri.argtypes = [_fp, _fp, _fp, _fp]
     L.orc_dist_point2lineseg.restype = C.c_float
@@ -199,6 +200,11 @@ class OracleSDF:
         out = np.empty(n, dtype=np.int32)
         if n:
             lib().orc_adj_get(self._h, int(v), out.ctypes.data_as(_ip))
+        return out
+
+    def sample_surface(self, n, seed, total_area):
+        out = np.empty((n, 3), dtype=np.float32)
+        lib().orc_sample_surface(self._h, n, seed, np.float32(total_area), _f(out))
         return out
 
     def kd_export(self):

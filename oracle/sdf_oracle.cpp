@@ -719,6 +719,57 @@ void orc_kd_stats(void* h, const float* pts, int n, double* out3) {
     out3[0] = (double)a / n, out3[1] = (double)b / n, out3[2] = (double)c / n;
 }
 
+// Impl::sample_surface (sdf.cpp:176-234) with the random draws replaced by a counter-based
+// stream: sample j takes its three uniforms from Philox4x32-10(key = seed, counter = j), mapped
+// to [0, 1 - eps] like uniform_real_distribution<float>(0, 1 - eps) (sdf.cpp:182-183).  The
+// reference draws from a time-seeded thread_local mt19937 (util.cpp:32-40), so only the
+// distribution can match it; against this restatement the GPU kernel is bit-exact.
+// face_area_cum is the reference's sequential fp32 running sum (sdf.cpp:196-201); total_area is
+// passed in (the reference uses Eigen's vectorised sum, whose association is not restated).
+static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                 uint32_t k1, uint32_t* out) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+static inline float u01(uint32_t x) {  // [0, 1 - eps]
+    return ((float)(x >> 8) * 5.9604644775390625e-8f) * (1.0f - FLT_EPSILON);
+}
+void orc_sample_surface(void* h, int64_t n, uint64_t seed, float total_area, float* out) {
+    Oracle* o = (Oracle*)h;
+    const int nf = o->nf;
+    if (nf == 0) return;
+    std::vector<float> cum(nf);
+    cum[0] = o->face_area[0];
+    for (int i = 1; i < nf; ++i) cum[i] = cum[i - 1] + o->face_area[i];
+    for (int64_t j = 0; j < n; ++j) {
+        uint32_t x[4];
+        philox4x32_10((uint32_t)j, (uint32_t)((uint64_t)j >> 32), 0u, 0u, (uint32_t)seed,
+                      (uint32_t)(seed >> 32), x);
+        const float r = u01(x[0]) * total_area;
+        int i = (int)(std::lower_bound(cum.begin(), cum.end(), r) - cum.begin());
+        i = std::max(std::min(i, nf - 1), 0);
+        const V3 a = o->vert(o->faces[3 * (size_t)i]), b = o->vert(o->faces[3 * (size_t)i + 1]),
+                 c = o->vert(o->faces[3 * (size_t)i + 2]);
+        const V3 ab = orc::sub(b, a), ac = orc::sub(c, a), bc = orc::sub(c, b);
+        V3 perp = orc::cross(bc, o->face_normal[i]);
+        const float pn = std::sqrt(orc::sqnorm(perp));  // normalized(): v / norm() (no-op if 0)
+        if (pn > 0.f) perp = {perp.x / pn, perp.y / pn, perp.z / pn};
+        const bool a_dir = orc::dot(ab, perp) < 0.0f;
+        const float u = u01(x[1]), w = u01(x[2]);
+        V3 p = {(a.x + u * ab.x) + w * ac.x, (a.y + u * ab.y) + w * ac.y, (a.z + u * ab.z) + w * ac.z};
+        const float bp = orc::dot(orc::sub(p, b), perp);
+        if ((bp >= 0.0f) != a_dir)
+            p = {p.x - (bp * perp.x) * 2.f, p.y - (bp * perp.y) * 2.f, p.z - (bp * perp.z) * 2.f};
+        out[3 * j] = p.x, out[3 * j + 1] = p.y, out[3 * j + 2] = p.z;
+    }
+}
+
 // standalone geometry entry points (for unit KATs)
 float orc_dist_point2tri(const float* p, const float* a, const float* b, const float* c) {
     V3 A = {a[0], a[1], a[2]}, B = {b[0], b[1], b[2]}, C = {c[0], c[1], c[2]};

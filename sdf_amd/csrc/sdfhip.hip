@@ -884,6 +884,63 @@ __global__ void k_fb_compact(const unsigned long long* __restrict__ amb_mask,
 }
 
 // =========================================================================================
+// sample_surface (sdf.cpp:176-234): face by inverse-CDF over the running sum of face areas,
+// then a uniform point of the parallelogram (a, ab, ac) reflected over bc.  The reference draws
+// from a time-seeded mt19937 (util.cpp:32-40); here sample j takes its three uniforms from
+// Philox4x32-10(key = seed, counter = j), so a call is reproducible and order independent.
+// =========================================================================================
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0, c1 = l1, c2 = n2, c3 = l0;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t x) {  // [0, 1 - eps], sdf.cpp:182-183
+    return ((float)(x >> 8) * 5.9604644775390625e-8f) * (1.0f - FLT_EPSILON);
+}
+__global__ void k_sample_surface(const float4* __restrict__ geo, const float* __restrict__ cum,
+                                 uint32_t nf, float total_area, uint64_t seed, int64_t n,
+                                 float* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t x[4];
+    philox4x32_10((uint32_t)j, (uint32_t)((uint64_t)j >> 32), 0u, 0u, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), x);
+    const float r = u01(x[0]) * total_area;
+    // std::lower_bound: first index whose running sum is not less than r (sdf.cpp:205-209)
+    uint32_t lo = 0, cnt = nf;
+    while (cnt > 0) {
+        const uint32_t half = cnt >> 1;
+        if (cum[lo + half] < r)
+            lo += half + 1, cnt -= half + 1;
+        else
+            cnt = half;
+    }
+    const uint32_t i = lo < nf - 1 ? lo : nf - 1;
+    const float4 g0 = geo[4 * (size_t)i], g1 = geo[4 * (size_t)i + 1], g2 = geo[4 * (size_t)i + 2];
+    const V3 a = {g0.x, g0.y, g0.z}, b = {g0.w, g1.x, g1.y}, c = {g1.z, g1.w, g2.x};
+    const V3 nrm = {g2.y, g2.z, g2.w};
+    const V3 ab = sdfk::sub(b, a), ac = sdfk::sub(c, a), bc = sdfk::sub(c, b);
+    V3 perp = sdfk::cross(bc, nrm);
+    const float pn = __builtin_sqrtf(sdfk::sqnorm(perp));  // normalized(): v / norm()
+    if (pn > 0.f) perp = {perp.x / pn, perp.y / pn, perp.z / pn};
+    const bool a_dir = sdfk::dot(ab, perp) < 0.0f;
+    const float u = u01(x[1]), w = u01(x[2]);
+    V3 p = {(a.x + u * ab.x) + w * ac.x, (a.y + u * ab.y) + w * ac.y, (a.z + u * ab.z) + w * ac.z};
+    const float bp = sdfk::dot(sdfk::sub(p, b), perp);
+    if ((bp >= 0.0f) != a_dir)
+        p = {p.x - (bp * perp.x) * 2.f, p.y - (bp * perp.y) * 2.f, p.z - (bp * perp.z) * 2.f};
+    out[3 * j] = p.x, out[3 * j + 1] = p.y, out[3 * j + 2] = p.z;
+}
+
+
+// =========================================================================================
 // update(): per-face precompute (sdf.cpp:50-70)
 // =========================================================================================
 struct RMat {
@@ -1437,6 +1494,9 @@ struct sdfhip_ctx {
     int32_t* d_adj_faces = nullptr;
     float4* d_geo = nullptr;
     float4* d_rface = nullptr;
+    float* d_area_cum = nullptr;  // running sum of face areas (sample_surface), valid iff cum_valid
+    bool cum_valid = false;
+    float total_area = 0.f;
     float* d_fbox = nullptr;
     float* d_normals = nullptr;
     float* d_areas = nullptr;
@@ -1584,6 +1644,7 @@ int update_device_side(sdfhip_ctx* h) {
                                                                h->d_fbox, h->d_normals, h->d_areas);
     HIPC(hipGetLastError());
     h->h_face_valid = false;
+    h->cum_valid = false;
     if (h->robust) {
         // the face order follows the ray-cast frame: rebuilt when R changed, refit otherwise
         if (!h->topo_built || std::memcmp(h->topo_R, h->R, sizeof(h->topo_R)) != 0)
@@ -2021,6 +2082,35 @@ int fetch_face_host(sdfhip_ctx* h) {
     return 0;
 }
 
+// sample_surface: running sum exactly as the reference builds it (sequential fp32,
+// sdf.cpp:196-201).  Unlike the reference, which computes face_area_cum once and keeps it across
+// update() (stale after a deformation), it is rebuilt after every update.
+int run_sample_surface(sdfhip_ctx* h, int64_t n, uint64_t seed, float* d_out, hipStream_t s) {
+    if (n < 0) return fail(SDFHIP_E_INVALID, "negative sample count");
+    if (h->nf == 0) return fail(SDFHIP_E_STATE, "No faces, can't sample surface.");
+    if (n == 0) return 0;
+    if (!d_out) return fail(SDFHIP_E_INVALID, "null output pointer");
+    if (!h->cum_valid) {
+        if (int rc = fetch_face_host(h)) return rc;
+        std::vector<float> cum(h->nf);
+        float run = 0.f, tot = 0.f;
+        for (uint32_t i = 0; i < h->nf; ++i) {
+            run = i ? run + h->h_areas[i] : h->h_areas[0];
+            cum[i] = run;
+            tot += h->h_areas[i];
+        }
+        h->total_area = tot;  // == sdfhip_surface_area
+        if (!h->d_area_cum)
+            if (int rc = dalloc(&h->d_area_cum, h->nf)) return rc;
+        HIPC(hipMemcpy(h->d_area_cum, cum.data(), sizeof(float) * h->nf, hipMemcpyHostToDevice));
+        h->cum_valid = true;
+    }
+    k_sample_surface<<<(uint32_t)((n + 255) / 256), 256, 0, s>>>(h->d_geo, h->d_area_cum, h->nf,
+                                                                 h->total_area, seed, n, d_out);
+    HIPC(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -2136,7 +2226,7 @@ void sdfhip_destroy(sdfhip_t* h) {
     DevGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_qn, h->d_kd_pts, h->d_kd_vind, h->d_adj_off,
-                    h->d_adj_faces, h->d_geo, h->d_rface, h->d_fbox, h->d_normals, h->d_areas,
+                    h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
                     h->topo.depthI, h->d_qkeys, h->d_qperm, h->d_qbounds, h->d_gstack, h->d_kd_pts4,
@@ -2314,6 +2404,32 @@ int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* o) {
         o->last_fallback_points = h->last_fb;
     }
     return 0;
+}
+int sdfhip_sample_surface_device(sdfhip_t* h, int64_t n, uint64_t seed, float* d_out, void* stream) {
+    if (!h) return fail(SDFHIP_E_INVALID, "null handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DevGuard g(h->device);
+    if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
+    return run_sample_surface(h, n, seed, d_out, (hipStream_t)stream);
+}
+int sdfhip_sample_surface(sdfhip_t* h, int64_t n, uint64_t seed, float* out) {
+    if (!h) return fail(SDFHIP_E_INVALID, "null handle");
+    if (n > 0 && !out) return fail(SDFHIP_E_INVALID, "null output pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DevGuard g(h->device);
+    if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
+    if (n <= 0) return run_sample_surface(h, n, seed, nullptr, h->stream);
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(float) * 3 * (size_t)n) != hipSuccess)
+        return fail(SDFHIP_E_NOMEM, "hipMalloc failed for %lld samples", (long long)n);
+    int rc = run_sample_surface(h, n, seed, d, h->stream);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(out, d, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(SDFHIP_E_HIP, "HIP error in sample_surface: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
 }
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
     if (!h || !key) return fail(SDFHIP_E_INVALID, "null handle/key");

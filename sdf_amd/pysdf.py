@@ -54,6 +54,7 @@ ABI_SYMBOLS = [
     "sdfhip_verts_mutable", "sdfhip_faces_mutable", "sdfhip_surface_area", "sdfhip_face_areas",
     "sdfhip_face_normals", "sdfhip_aabb", "sdfhip_adj_faces", "sdfhip_get_stats",
     "sdfhip_set_option", "sdfhip_last_error", "sdfhip_version",
+    "sdfhip_sample_surface", "sdfhip_sample_surface_device",
 ]
 
 
@@ -110,6 +111,8 @@ def load_library():
     L.sdfhip_face_normals.argtypes = [vp, _fp]
     L.sdfhip_aabb.argtypes = [vp, _fp]
     L.sdfhip_adj_faces.argtypes = [vp, C.c_uint32, C.POINTER(_ip)]
+    L.sdfhip_sample_surface.argtypes = [vp, C.c_int64, C.c_uint64, _fp]
+    L.sdfhip_sample_surface_device.argtypes = [vp, C.c_int64, C.c_uint64, vp, vp]
     L.sdfhip_get_stats.argtypes = [vp, C.POINTER(_Stats)]
     L.sdfhip_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.sdfhip_last_error.restype = C.c_char_p
@@ -252,34 +255,30 @@ class SDF:
                                              out.ctypes.data_as(_ip)))
         return out
 
-    def sample_surface(self, num_points):
-        """Sample num_points uniformly random points on the mesh surface (sdf.cpp:176-234):
-        pick a face with probability proportional to its area, then a uniform point in it
-        (parallelogram sample reflected over bc).  Host-side numpy: outside the GPU hot path
-        (SURVEY.md §8f), random by construction so only distribution-level parity applies."""
-        areas = self.face_areas
-        if areas.shape[0] == 0:
+    def sample_surface(self, num_points, seed=None, device=False):
+        """Sample num_points uniformly random points on the mesh surface (sdf.cpp:176-234,
+        pybind.cpp:31): a face with probability proportional to its area, then a uniform point
+        in it (parallelogram sample reflected over bc).  Runs on the GPU (`k_sample_surface`).
+        `seed` (extension; default: fresh entropy, like the reference's time-seeded generator)
+        makes the call reproducible; `device=True` returns a torch tensor on the handle's GPU."""
+        n = int(num_points)
+        if self.faces.shape[0] == 0:
             import sys
-            print("ERROR: No faces, can't sample surface.", file=sys.stderr)
+            print("ERROR: No faces, can't sample surface.", file=sys.stderr)  # sdf.cpp:178
             return np.zeros((0, 3), dtype=np.float32)
-        rng = np.random.default_rng()
-        cum = np.cumsum(areas, dtype=np.float32)
-        r = rng.uniform(0, 1, num_points).astype(np.float32) * np.float32(self.surface_area)
-        fi = np.clip(np.searchsorted(cum, r, side="left"), 0, areas.shape[0] - 1)
-        F = self.faces[fi].astype(np.int64)
-        V = self.verts
-        a, b, c = V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]
-        ab, ac, bc = b - a, c - a, c - b
-        perp = np.cross(bc, self.face_normals[fi])
-        perp /= np.linalg.norm(perp, axis=1, keepdims=True)
-        a_dir = (ab * perp).sum(1) < 0
-        u = rng.uniform(0, 1, (num_points, 1)).astype(np.float32)
-        w = rng.uniform(0, 1, (num_points, 1)).astype(np.float32)
-        res = a + u * ab + w * ac
-        bp = ((res - b) * perp).sum(1)
-        flip = (bp >= 0) != a_dir
-        res[flip] -= (bp[flip, None] * perp[flip]) * 2.0
-        return res.astype(np.float32)
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")
+        seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        if device:
+            import torch
+            dev = torch.device("cuda", self._L.sdfhip_device(self._h))
+            out = torch.empty((max(n, 0), 3), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _check(self._L.sdfhip_sample_surface_device(self._h, n, seed, out.data_ptr(), stream))
+            return out
+        out = np.empty((max(n, 0), 3), dtype=np.float32)
+        _check(self._L.sdfhip_sample_surface(self._h, n, seed, out.ctypes.data_as(_fp)))
+        return out
 
     # ---- rotation injection (no counterpart: the reference's R is private + random) -----
     def set_raycast_axes(self, R, pin=True):
