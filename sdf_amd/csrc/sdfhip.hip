@@ -7,7 +7,7 @@
 // Structures (all resident in HBM, sized to sit in L2 / Infinity Cache):
 //   kd_pn      64 B / internal node of the strict nanoflann-equivalent vertex kd-tree
 //              (tight child boxes + divlow/divhigh + child refs), kd_split 4 B / node
-//   kd_pts     12 B / vertex, in tree (vind) order: a leaf is a contiguous run
+//   kd_pts4    16 B / padded tree position, in tree (vind) order: a leaf is a contiguous run
 //   geo        64 B / face: a, b, c, unit normal, area (world frame) for dist_point2tri
 //   rnodes     32 B / node: threaded (stackless, pre-order + skip link) LBVH over the
 //              rotated-frame face AABBs; Morton codes -> LDS radix sort -> Karras hierarchy,
@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <future>
 #include <mutex>
 #include <thread>
 #include <random>
@@ -77,7 +78,6 @@ struct MeshDev {
     const uint32_t* kd_split;
     const float4* kd_qn;  // 4-wide collapse for the packet pass: 128 B {box[4][6], ref[4], pad}
     uint32_t kd_qroot;
-    const float* kd_pts;
     const int32_t* kd_vind;
     uint32_t kd_root;
     float bb[6];  // mesh AABB == kd root bbox
@@ -195,9 +195,10 @@ __device__ __forceinline__ int kd_nearest(const MeshDev& M, float qx, float qy, 
         }
         if (!near_skipped) {  // leaf (nanoflann.hpp:1350-1367); metric ((0+dx^2)+dy^2)+dz^2 (432-440)
             const uint32_t left = (cur & sdfk::KD_REF_MASK) >> 4, cnt = cur & 15u;
-            const float* p = M.kd_pts + 3 * (size_t)left;
+            const float4* p = M.kd_pts4 + left;
             for (uint32_t k = 0; k < cnt; ++k) {
-                const float dx = qx - p[3 * k], dy = qy - p[3 * k + 1], dz = qz - p[3 * k + 2];
+                const float4 pk = p[k];
+                const float dx = qx - pk.x, dy = qy - pk.y, dz = qz - pk.z;
                 const float dist = (dx * dx + dy * dy) + dz * dz;
                 if (dist < best) {  // strict: first visited wins ties (nanoflann.hpp:184)
                     best = dist;
@@ -423,7 +424,8 @@ __device__ __forceinline__ float calc_tail(const MeshDev& M, V3 p, bool trunc_aa
     V3 vnn = {0.f, 0.f, 0.f};
     if (pos >= 0) {
         const int vi = M.kd_vind[pos];
-        vnn = {M.kd_pts[3 * (size_t)pos], M.kd_pts[3 * (size_t)pos + 1], M.kd_pts[3 * (size_t)pos + 2]};
+        const float4 pv = M.kd_pts4[pos];
+        vnn = {pv.x, pv.y, pv.z};
         const uint32_t fb = M.adj_off[vi], fe = M.adj_off[vi + 1];
         for (uint32_t k = fb; k < fe; ++k) {
             const int f = M.adj_faces[k];
@@ -1475,7 +1477,7 @@ struct sdfhip_ctx {
     float4* d_kd_qn = nullptr;
     size_t kd_quads_cap = 0;
     uint32_t* d_kd_split = nullptr;
-    float* d_kd_pts = nullptr;
+    std::vector<float> perm_pts4;  // host staging of kd_pts4, kept across updates
     int32_t* d_kd_vind = nullptr;
     size_t kd_nodes_cap = 0, kd_pos_cap = 0;
     float4* d_kd_pts4 = nullptr;
@@ -1657,22 +1659,69 @@ int update_device_side(sdfhip_ctx* h) {
 int do_update(sdfhip_ctx* h, bool draw_R) {
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = h->stream;
+    // mesh AABB (sdf.cpp:36-37; == the kd root box): needed by the device side before the tree
+    for (int d = 0; d < 6; ++d) h->aabb[d] = 0.f;
+    if (h->nv) {
+        float lo[3] = {h->h_verts[0], h->h_verts[1], h->h_verts[2]}, hi[3] = {lo[0], lo[1], lo[2]};
+        for (size_t i = 1; i < h->nv; ++i)
+            for (int d = 0; d < 3; ++d) {
+                const float v = h->h_verts[3 * i + d];
+                if (v < lo[d]) lo[d] = v;
+                if (v > hi[d]) hi[d] = v;
+            }
+        for (int d = 0; d < 3; ++d) h->aabb[d] = lo[d], h->aabb[d + 3] = hi[d];
+    }
+    if (h->robust && draw_R && !h->R_pinned) draw_rotation(h);
+    // Device side (vertex upload, per-face precompute, LBVH order / refit) does not depend on
+    // the kd-tree: it runs from a helper thread while this thread builds the tree.
+    if (h->nv)
+        HIPC(hipMemcpyAsync(h->d_verts, h->h_verts, sizeof(float) * 3 * (size_t)h->nv,
+                            hipMemcpyHostToDevice, s));
+    std::string dev_err;
+    auto dev_side = std::async(std::launch::async, [h, &dev_err]() -> int {
+        if (hipSetDevice(h->device) != hipSuccess) return SDFHIP_E_HIP;
+        const int rc = update_device_side(h);
+        if (rc) dev_err = g_err;  // g_err is thread local
+        return rc;
+    });
     // strict kd-tree on the host (sdf.cpp:32 kd_tree.rebuild())
+    auto tk = std::chrono::steady_clock::now();
     h->kd.build(h->h_verts, h->nv, (int)h->opt_build_threads);
-    auto t1 = std::chrono::steady_clock::now();
-    h->last_kd_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    h->last_kd_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk).count();
+    // vertices in (padded) tree order; sentinel slots are far away: their distance is +inf
+    const size_t npos = h->kd.pos_vert.size();
+    const size_t nalloc = npos + 16;
+    auto fill = std::async(std::launch::async, [h, npos, nalloc]() {
+        h->perm_pts4.resize(4 * nalloc);
+        float* dst = h->perm_pts4.data();
+        for (size_t i = 0; i < nalloc; ++i) {
+            const int32_t vi = i < npos ? h->kd.pos_vert[i] : -1;
+            if (vi < 0) {
+                dst[4 * i] = dst[4 * i + 1] = dst[4 * i + 2] = dst[4 * i + 3] = 3.0e38f;
+            } else {
+                const float* src = h->h_verts + 3 * (size_t)vi;
+                dst[4 * i] = src[0], dst[4 * i + 1] = src[1], dst[4 * i + 2] = src[2], dst[4 * i + 3] = 3.0e38f;
+            }
+        }
+    });
     h->kd.build_quads();
-    std::memcpy(h->aabb, h->kd.bbox, sizeof(h->aabb));  // sdf.cpp:36-37
+    fill.get();
+    const int rc_dev = dev_side.get();
+    if (rc_dev) return fail(rc_dev, "%s", dev_err.empty() ? "device-side update failed" : dev_err.c_str());
+    if (h->kd.nodes.size() >= (size_t)KD_MARK) return fail(SDFHIP_E_INVALID, "kd-tree too large");
     if (h->kd.quads.size() > h->kd_quads_cap) {
         if (int rc = dalloc(&h->d_kd_qn, 8 * h->kd.quads.size())) return rc;
         h->kd_quads_cap = h->kd.quads.size();
     }
-    if (h->kd.nodes.size() >= (size_t)KD_MARK)
-        return fail(SDFHIP_E_INVALID, "kd-tree too large");
     if (h->kd.nodes.size() > h->kd_nodes_cap) {
         if (int rc = dalloc(&h->d_kd_pn, 4 * h->kd.nodes.size())) return rc;
         if (int rc = dalloc(&h->d_kd_split, h->kd.nodes.size())) return rc;
         h->kd_nodes_cap = h->kd.nodes.size();
+    }
+    if (nalloc > h->kd_pos_cap) {
+        if (int rc = dalloc(&h->d_kd_pts4, nalloc)) return rc;
+        if (int rc = dalloc(&h->d_kd_vind, nalloc)) return rc;
+        h->kd_pos_cap = nalloc;
     }
     {   // ambiguity factor of the packet pass: c = (1 + w_th + 4u) rounded up, w_th = u(3.02 D + 11.2)
         const double u = 5.9604644775390625e-8;
@@ -1684,33 +1733,10 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
         if ((double)c2 < (double)c * (double)c * (1.0 + 4.0 * u)) c2 = std::nextafter(c2, 2.0f);
         h->amb_c2 = c2;
     }
-    // vertices in (padded) tree order; sentinel slots are far away: their distance is +inf
-    const size_t npos = h->kd.pos_vert.size();
-    const size_t nalloc = npos + 16;  // the packet pass reads one chunk (4 slots) past a group
-    if (nalloc > h->kd_pos_cap) {
-        if (int rc = dalloc(&h->d_kd_pts, 3 * nalloc)) return rc;
-        if (int rc = dalloc(&h->d_kd_pts4, nalloc)) return rc;
-        if (int rc = dalloc(&h->d_kd_vind, nalloc)) return rc;
-        h->kd_pos_cap = nalloc;
-    }
-    std::vector<float> perm_pts(3 * nalloc, 3.0e38f);
-    std::vector<float> perm_pts4(4 * nalloc, 3.0e38f);
-    for (size_t i = 0; i < npos; ++i) {
-        const int32_t vi = h->kd.pos_vert[i];
-        if (vi < 0) continue;
-        const float* src = h->h_verts + 3 * (size_t)vi;
-        perm_pts[3 * i] = src[0], perm_pts[3 * i + 1] = src[1], perm_pts[3 * i + 2] = src[2];
-        perm_pts4[4 * i] = src[0], perm_pts4[4 * i + 1] = src[1], perm_pts4[4 * i + 2] = src[2];
-    }
-    if (h->nv)
-        HIPC(hipMemcpyAsync(h->d_verts, h->h_verts, sizeof(float) * 3 * (size_t)h->nv,
-                            hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpyAsync(h->d_kd_pts, perm_pts.data(), sizeof(float) * perm_pts.size(),
-                        hipMemcpyHostToDevice, s));
     if (npos)
         HIPC(hipMemcpyAsync(h->d_kd_vind, h->kd.pos_vert.data(), sizeof(int32_t) * npos,
                             hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpyAsync(h->d_kd_pts4, perm_pts4.data(), sizeof(float) * perm_pts4.size(),
+    HIPC(hipMemcpyAsync(h->d_kd_pts4, h->perm_pts4.data(), sizeof(float) * 4 * nalloc,
                         hipMemcpyHostToDevice, s));
     if (!h->kd.nodes.empty()) {
         HIPC(hipMemcpyAsync(h->d_kd_pn, h->kd.nodes.data(), sizeof(sdfk::KdNodeH) * h->kd.nodes.size(),
@@ -1720,10 +1746,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
         HIPC(hipMemcpyAsync(h->d_kd_qn, h->kd.quads.data(), sizeof(sdfk::KdQuadH) * h->kd.quads.size(),
                             hipMemcpyHostToDevice, s));
     }
-    HIPC(hipStreamSynchronize(s));  // perm_pts is pageable and about to go out of scope
-    if (h->robust && draw_R && !h->R_pinned) draw_rotation(h);
-    if (int rc = update_device_side(h)) return rc;
-    HIPC(hipStreamSynchronize(s));
+    HIPC(hipStreamSynchronize(s));  // host arrays are pageable and rebuilt by the next update
     h->last_update_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
@@ -1735,7 +1758,6 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.kd_split = h->d_kd_split;
     M.kd_qn = h->d_kd_qn;
     M.kd_qroot = h->kd.quad_root;
-    M.kd_pts = h->d_kd_pts;
     M.kd_vind = h->d_kd_vind;
     M.kd_root = h->kd.root_ref;
     for (int d = 0; d < 6; ++d) M.bb[d] = h->aabb[d];
@@ -2225,7 +2247,7 @@ void sdfhip_destroy(sdfhip_t* h) {
     if (!h) return;
     DevGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_qn, h->d_kd_pts, h->d_kd_vind, h->d_adj_off,
+    void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_qn, h->d_kd_vind, h->d_adj_off,
                     h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
