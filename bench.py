@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid", action="store_true")
     ap.add_argument("--no-sort", action="store_true")
+    # rehearsal of the N>1 path on a box with one GPU: every rank on cuda:0, mesh broadcast over gloo
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--one-device", action="store_true")
     return ap.parse_args()
 
 
@@ -85,12 +88,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    if a.one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     # ---- mesh: built on rank 0, replicated by RCCL broadcast (sdf_amd/distributed.py) -------
     res = a.mesh_res
@@ -101,7 +109,7 @@ def main():
         R = meshes.random_rotation(1234)
     if dist is not None:
         from sdf_amd.distributed import broadcast_mesh
-        v, f, R = broadcast_mesh(v, f, R, src=0, device=dev)
+        v, f, R = broadcast_mesh(v, f, R, src=0, device=dev if a.backend == "nccl" else "cpu")
     s = sdf_amd.SDF(v, f, robust=True, copy=True, device=local)
     s.set_raycast_axes(R)
     if a.no_sort:
@@ -138,7 +146,7 @@ def main():
     st = s.stats
     s.set_option("profile", 0)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

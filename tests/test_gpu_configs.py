@@ -98,3 +98,52 @@ def test_update_from_device_tensor():
     o = po.OracleSDF(v1, f, True, R)
     pts = np.random.default_rng(1).uniform(-1, 1, (50_000, 3)).astype(np.float32)
     assert same_float(s(pts), o(pts)).all() and (s.verts == v1).all()
+
+
+def test_config4_full_shard_device_resident_properties():
+    """BASELINE config 4 at its full per-GPU size (125M device-resident points, the bench.py
+    workload): the CPU oracle cannot cover it, so size-independent properties — results do not
+    depend on which batch a point is evaluated in (the Morton sort, the wave it lands in and
+    the chunking all change), sign == contains, the analytic torus — plus an oracle check of a
+    random sample of the very rows of the big result."""
+    import torch
+    v, f = meshes.torus(424, 424)
+    R = meshes.random_rotation(1234)
+    s = SDF(v, f, robust=True)
+    s.set_raycast_axes(R)
+    dev = torch.device("cuda", 0)
+    n = 125_000_000
+    g = torch.Generator(device=dev).manual_seed(7)
+    pts = torch.rand((n, 3), device=dev, generator=g, dtype=torch.float32).mul_(2).sub_(1)
+    d = s(pts)
+    c = s.contains(pts)
+    nn = s.nn(pts)
+    assert s.stats["last_fallback_points"] >= 0
+    assert bool(((d > 0) == c)[d != 0].all())
+    rho = torch.sqrt(pts[:, 0] ** 2 + pts[:, 1] ** 2) - 0.7
+    ana = 0.24 - torch.sqrt(rho ** 2 + pts[:, 2] ** 2)
+    far = ana.abs() > 2e-3
+    assert bool(((ana > 0) == c)[far].all())
+    assert float((d - ana).abs().max()) < 2e-3
+    del rho, ana, far
+    # nn is a true nearest vertex: no vertex of the mesh is closer (checked through |sdf| <= dist)
+    tv = torch.from_numpy(v).to(dev)
+    dn = (tv[nn.long()] - pts).norm(dim=1)
+    assert bool((d.abs() <= dn * (1 + 1e-6)).all())
+    del dn
+    # batch independence: a strided subset evaluated alone gives the same bits
+    idx = torch.arange(0, n, 97, device=dev)
+    sub = pts[idx].contiguous()
+    assert bool((s(sub).view(torch.int32) == d[idx].view(torch.int32)).all())
+    assert bool((s.contains(sub) == c[idx]).all())
+    assert bool((s.nn(sub) == nn[idx]).all())
+    # and a slice through the host entry points (chunked, overlapped copies)
+    hs = pts[: 3_000_000].cpu().numpy()
+    assert same_float(s(hs), d[: 3_000_000].cpu().numpy()).all()
+    # oracle on a random sample of rows of the big result
+    k = torch.randint(0, n, (200_000,), device=dev, generator=g)
+    hp = pts[k].cpu().numpy()
+    o = po.OracleSDF(v, f, True, R)
+    assert same_float(d[k].cpu().numpy(), o(hp)).all()
+    assert (c[k].cpu().numpy() == o.contains(hp)).all()
+    assert (nn[k].cpu().numpy() == o.nn(hp)).all()
