@@ -92,6 +92,14 @@ struct MeshDev {
     const float4* rnodes;
     uint32_t n_rnodes;
     const float4* rface;
+    // column grid over (x', y') of the ray-cast frame: cell -> faces whose rotated AABB touches it
+    const float* fbox;          // per face: rotated AABB min xyz, max xyz
+    const uint32_t* gr_start;   // [g*g + 1]
+    const uint32_t* gr_items;   // face ids, cell by cell
+    const uint32_t* gr_big;     // faces spanning too many cells: tested by every query
+    uint32_t gr_nbig;
+    int gr_g;
+    float gr_o0, gr_o1, gr_inv0, gr_inv1;
     float R[9];
 };
 
@@ -324,6 +332,51 @@ __device__ __forceinline__ int ray_x_pos(const MeshDev& M, V3 q) {
     return c;
 }
 
+// Column grid.  The z+ / z- rays of a query are the column (q.x, q.y): the only faces that can
+// pass the Overlap test are those whose rotated AABB contains (q.x, q.y) in x and y, and every
+// such face is registered in the cell of (q.x, q.y): grid_cell is monotone non-decreasing in v
+// (subtract, multiply by a positive constant, floor, clamp), so mn <= q <= mx implies
+// cell(mn) <= cell(q) <= cell(mx).  Each lane walks its own cell's list — O(1) to find, a
+// handful of faces long — and applies the reference's exact per-face predicate; XOR parity is
+// order independent, so the result equals the R-tree search's (sdf.cpp:292-315).
+__device__ __forceinline__ int grid_cell(float v, float o, float inv, int g) {
+    const float f = floorf((v - o) * inv);
+    if (!(f > 0.f)) return 0;  // also NaN
+    if (f >= (float)(g - 1)) return g - 1;
+    return (int)f;
+}
+__device__ __forceinline__ void ray_face_z(const MeshDev& M, V3 q, uint32_t face, int& zp, int& zm) {
+    const float* bx = M.fbox + 6 * (size_t)face;
+    const float mnx = bx[0], mny = bx[1], mnz = bx[2], mxx = bx[3], mxy = bx[4], mxz = bx[5];
+    if ((q.x > mxx || mnx > q.x) || (q.y > mxy || mny > q.y)) return;  // Overlap, x and y
+    const bool okp = !(q.z > mxz || mnz > FLT_MAX);   // box [q.z, FLT_MAX]
+    const bool okm = !(-FLT_MAX > mxz || mnz > q.z);  // box [-FLT_MAX, q.z]
+    const float4 f0 = M.rface[3 * (size_t)face];      // a'.xyz b'.x
+    const float4 f1 = M.rface[3 * (size_t)face + 1];  // b'.yz c'.xy
+    const float4 f2 = M.rface[3 * (size_t)face + 2];  // c'.z n'.xyz
+    const V3 nr = {f2.y, f2.z, f2.w};
+    const V3 dv = sdfk::sub(q, V3{f0.x, f0.y, f0.z});
+    const float s = sdfk::dot(nr, dv) * nr.z;  // sdf.cpp:301-302, ax_idx = 2
+    const bool pos = s > 0.f;                  // z- needs pos, z+ needs !pos
+    if (pos ? okm : okp) {
+        if (sdfk::bary2d_inside(q.x, q.y, f0.x, f0.y, f0.w, f1.x, f1.z, f1.w)) {
+            if (pos)
+                zm ^= 1;
+            else
+                zp ^= 1;
+        }
+    }
+}
+__device__ __forceinline__ void ray_z_pair_grid(const MeshDev& M, V3 q, int& zp, int& zm) {
+    zp = 0;
+    zm = 0;
+    const int cx = grid_cell(q.x, M.gr_o0, M.gr_inv0, M.gr_g), cy = grid_cell(q.y, M.gr_o1, M.gr_inv1, M.gr_g);
+    const uint32_t c = (uint32_t)cy * (uint32_t)M.gr_g + (uint32_t)cx;
+    const uint32_t e = M.gr_start[c + 1];
+    for (uint32_t k = M.gr_start[c]; k < e; ++k) ray_face_z(M, q, M.gr_items[k], zp, zm);
+    for (uint32_t k = 0; k < M.gr_nbig; ++k) ray_face_z(M, q, M.gr_big[k], zp, zm);
+}
+
 // Wave-cooperative form of ray_z_pair for 64 Morton-adjacent queries: the threaded walk is
 // wave-uniform (a node is entered when ANY lane's point is inside its xy box; nodes and faces
 // come in by scalar loads) and each lane applies the exact per-face predicate to the leaves
@@ -375,8 +428,8 @@ __device__ __forceinline__ float raycast_packet(const MeshDev& M, V3 p, bool val
                                   p.z < M.bb[2] || p.z > M.bb[5]);  // sdf.cpp:278-283
     if (__ballot(inbox) == 0ull) return -1.f;
     const V3 q = sdfk::mulR(p, M.R);
-    int zp, zm;
-    ray_z_pair_packet(M, q, inbox, zp, zm);
+    int zp = 0, zm = 0;
+    if (inbox) ray_z_pair_grid(M, q, zp, zm);
     int result = zp + zm;
     if (inbox && result == 1) result += ray_x_pos(M, q);  // tiebreaker (sdf.cpp:326), rare
     return (inbox && result > 1) ? 1.0f : -1.0f;
@@ -391,7 +444,7 @@ __device__ __forceinline__ float raycast(const MeshDev& M, V3 p, int* detail) {
         return -1.f;
     const V3 q = sdfk::mulR(p, M.R);
     int zp, zm;
-    ray_z_pair(M, q, zp, zm);
+    ray_z_pair_grid(M, q, zp, zm);
     int result = zp + zm;
     if (detail) detail[0] = zp, detail[1] = zm;
     if (result == 1) {  // tiebreaker (sdf.cpp:326)
@@ -1435,6 +1488,38 @@ __global__ void k_lbvh_leaf_boxes(int n, const uint32_t* __restrict__ posL,
     rnodes[2 * (size_t)pos + 1] = w;
 }
 
+// column grid build: count (or fill) the cells each face's rotated AABB touches
+struct GridParams {
+    int g;
+    float o0, o1, inv0, inv1;
+};
+constexpr uint32_t GRID_BIG = 256;  // faces touching more cells go to the "big" list
+template <bool FILL>
+__global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridParams G,
+                             uint32_t* __restrict__ cells /* counts | cursors */,
+                             uint32_t* __restrict__ items, uint32_t* __restrict__ big,
+                             uint32_t* __restrict__ nbig) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    const float* b = fbox + 6 * (size_t)f;
+    const int x0 = grid_cell(b[0], G.o0, G.inv0, G.g), x1 = grid_cell(b[3], G.o0, G.inv0, G.g);
+    const int y0 = grid_cell(b[1], G.o1, G.inv1, G.g), y1 = grid_cell(b[4], G.o1, G.inv1, G.g);
+    if (x1 < x0 || y1 < y0) return;  // NaN box: the face can never pass Overlap
+    const uint32_t nc = (uint32_t)(x1 - x0 + 1) * (uint32_t)(y1 - y0 + 1);
+    if (nc > GRID_BIG) {
+        if (!FILL) big[atomicAdd(nbig, 1u)] = f;
+        return;
+    }
+    for (int y = y0; y <= y1; ++y)
+        for (int x = x0; x <= x1; ++x) {
+            const uint32_t c = (uint32_t)y * (uint32_t)G.g + (uint32_t)x;
+            if (FILL)
+                items[atomicAdd(&cells[c], 1u)] = f;
+            else
+                atomicAdd(&cells[c], 1u);
+        }
+}
+
 // one launch per depth, deepest first: children are complete (previous launch / leaves)
 __global__ void k_lbvh_fit(int n, LbvhTopo T, uint32_t depth, float4* __restrict__ rnodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1500,6 +1585,17 @@ struct sdfhip_ctx {
     bool cum_valid = false;
     float total_area = 0.f;
     float* d_fbox = nullptr;
+    // column grid (rebuilt by every update: face boxes move)
+    uint32_t* d_gr_start = nullptr;
+    uint32_t* d_gr_cursor = nullptr;
+    uint32_t* d_gr_items = nullptr;
+    uint32_t* d_gr_big = nullptr;
+    uint32_t* d_gr_nbig = nullptr;
+    uint32_t* d_gr_s1 = nullptr;
+    uint32_t* d_gr_s2 = nullptr;
+    size_t gr_cells_cap = 0, gr_items_cap = 0;
+    uint32_t gr_nbig = 0, gr_entries = 0;
+    GridParams gr = {1, 0.f, 0.f, 0.f, 0.f};
     float* d_normals = nullptr;
     float* d_areas = nullptr;
     float4* d_rnodes = nullptr;
@@ -1635,6 +1731,73 @@ int refit(sdfhip_ctx* h) {
     return 0;
 }
 
+// column grid over the rotated face boxes (d_fbox must be current on the stream)
+int build_grid(sdfhip_ctx* h) {
+    const uint32_t n = h->nf;
+    hipStream_t s = h->stream;
+    if (n == 0) return 0;
+    // range of x', y': rotated corners of the world AABB (covers every face box up to rounding;
+    // anything outside lands in the clamped border cells, on both the face and the query side)
+    float lo[2] = {FLT_MAX, FLT_MAX}, hi[2] = {-FLT_MAX, -FLT_MAX};
+    for (int c = 0; c < 8; ++c) {
+        const float x = h->aabb[(c & 1) ? 3 : 0], y = h->aabb[(c & 2) ? 4 : 1], z = h->aabb[(c & 4) ? 5 : 2];
+        for (int d = 0; d < 2; ++d) {
+            const float r = x * h->R[d] + y * h->R[3 + d] + z * h->R[6 + d];
+            lo[d] = r < lo[d] ? r : lo[d];
+            hi[d] = r > hi[d] ? r : hi[d];
+        }
+    }
+    int g = (int)std::sqrt((double)n);
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    if (!h->d_gr_nbig) {
+        if (int rc = dalloc(&h->d_gr_nbig, 1)) return rc;
+        if (int rc = dalloc(&h->d_gr_big, n)) return rc;
+    }
+    for (;;) {
+        GridParams G;
+        G.g = g;
+        G.o0 = lo[0], G.o1 = lo[1];
+        const float e0 = hi[0] - lo[0], e1 = hi[1] - lo[1];
+        G.inv0 = (e0 > 0.f && e0 < FLT_MAX) ? (float)g / e0 : 0.f;
+        G.inv1 = (e1 > 0.f && e1 < FLT_MAX) ? (float)g / e1 : 0.f;
+        const size_t cells = (size_t)g * g + 1;
+        if (cells > h->gr_cells_cap) {
+            if (int rc = dalloc(&h->d_gr_start, cells)) return rc;
+            if (int rc = dalloc(&h->d_gr_cursor, cells)) return rc;
+            if (int rc = dalloc(&h->d_gr_s1, cells / 2048 + 4)) return rc;
+            if (int rc = dalloc(&h->d_gr_s2, cells / 2048 / 2048 + 4)) return rc;
+            h->gr_cells_cap = cells;
+        }
+        HIPC(hipMemsetAsync(h->d_gr_start, 0, sizeof(uint32_t) * cells, s));
+        HIPC(hipMemsetAsync(h->d_gr_nbig, 0, sizeof(uint32_t), s));
+        k_grid_faces<false><<<(n + 255) / 256, 256, 0, s>>>(h->d_fbox, n, G, h->d_gr_start, nullptr,
+                                                            h->d_gr_big, h->d_gr_nbig);
+        exclusive_scan_u32(h->d_gr_start, (uint32_t)cells, h->d_gr_s1, h->d_gr_s2, s);
+        uint32_t total = 0, nbig = 0;
+        HIPC(hipMemcpyAsync(&total, h->d_gr_start + (cells - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPC(hipMemcpyAsync(&nbig, h->d_gr_nbig, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPC(hipStreamSynchronize(s));
+        // many faces much larger than a cell: a coarser grid keeps the lists (and memory) short
+        if (((size_t)total > 16 * (size_t)n + 4096 || (size_t)nbig > (size_t)n / 64 + 16) && g > 1) {
+            g = g / 2;
+            continue;
+        }
+        if ((size_t)total + 1 > h->gr_items_cap) {
+            const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
+            if (int rc = dalloc(&h->d_gr_items, cap)) return rc;
+            h->gr_items_cap = cap;
+        }
+        HIPC(hipMemcpyAsync(h->d_gr_cursor, h->d_gr_start, sizeof(uint32_t) * cells, hipMemcpyDeviceToDevice, s));
+        k_grid_faces<true><<<(n + 255) / 256, 256, 0, s>>>(h->d_fbox, n, G, h->d_gr_cursor, h->d_gr_items,
+                                                           h->d_gr_big, h->d_gr_nbig);
+        HIPC(hipGetLastError());
+        h->gr = G;
+        h->gr_nbig = nbig;
+        h->gr_entries = total;
+        return 0;
+    }
+}
+
 // rotation-dependent + vertex-dependent precompute; verts must already be in d_verts
 int update_device_side(sdfhip_ctx* h) {
     hipStream_t s = h->stream;
@@ -1652,6 +1815,7 @@ int update_device_side(sdfhip_ctx* h) {
         if (!h->topo_built || std::memcmp(h->topo_R, h->R, sizeof(h->topo_R)) != 0)
             if (int rc = build_topology(h)) return rc;
         if (int rc = refit(h)) return rc;
+        if (int rc = build_grid(h)) return rc;
     }
     return 0;
 }
@@ -1770,6 +1934,13 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.rnodes = h->d_rnodes;
     M.n_rnodes = h->robust ? h->n_rnodes : 0;
     M.rface = h->d_rface;
+    M.fbox = h->d_fbox;
+    M.gr_start = h->d_gr_start;
+    M.gr_items = h->d_gr_items;
+    M.gr_big = h->d_gr_big;
+    M.gr_nbig = h->robust ? h->gr_nbig : 0;
+    M.gr_g = h->gr.g;
+    M.gr_o0 = h->gr.o0, M.gr_o1 = h->gr.o1, M.gr_inv0 = h->gr.inv0, M.gr_inv1 = h->gr.inv1;
     for (int d = 0; d < 9; ++d) M.R[d] = h->R[d];
     return M;
 }
@@ -2248,7 +2419,8 @@ void sdfhip_destroy(sdfhip_t* h) {
     DevGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_qn, h->d_kd_vind, h->d_adj_off,
-                    h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
+                    h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_gr_start, h->d_gr_cursor, h->d_gr_items,
+                    h->d_gr_big, h->d_gr_nbig, h->d_gr_s1, h->d_gr_s2, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
                     h->topo.depthI, h->d_qkeys, h->d_qperm, h->d_qbounds, h->d_gstack, h->d_kd_pts4,

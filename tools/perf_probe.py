@@ -13,6 +13,7 @@ ap.add_argument("--grid", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--robust", type=int, default=1)
 ap.add_argument("--only", default="")
+ap.add_argument("--nosort", type=int, default=0)
 ap.add_argument("--group", type=int, default=0, help="packet_group option (0 = library default)")
 a = ap.parse_args()
 v, f = meshes.torus(a.res, a.res)
@@ -29,6 +30,8 @@ else:
     g = torch.Generator(device=dev).manual_seed(7)
     pts = torch.rand((a.n, 3), device=dev, generator=g).mul_(2).sub_(1)
 n = pts.shape[0]
+if a.nosort:
+    s.set_option("sort_queries", 0)
 print("stats", s.stats)
 s.set_option("profile", 1)
 for name, fn in (("nn", s.nn), ("contains", s.contains), ("sdf", s.__call__)):
