@@ -123,6 +123,33 @@ def test_edge_cases():
     assert s.adj_faces(0) == po.OracleSDF(v, f, True).adj_faces(0).tolist()
 
 
+def test_ray_grid_big_faces_and_coarsening():
+    """column grid of the parity rays: faces spanning many cells (the "big" list), a soup of
+    large overlapping faces (the grid coarsens itself) and points outside the grid's range"""
+    rng = np.random.default_rng(11)
+    R = meshes.random_rotation(5)
+    # (a) fine sphere inside a huge box: 12 faces cover every cell
+    vs, fs = meshes.icosphere(4, radius=0.5)
+    vb, fb = meshes.cube(0.9)
+    v = np.concatenate([vs, vb]).astype(np.float32)
+    f = np.concatenate([fs, fb + vs.shape[0]]).astype(np.uint32)
+    # (b) 3000 large random triangles, not watertight
+    v2 = rng.uniform(-1, 1, (9000, 3)).astype(np.float32)
+    f2 = np.arange(9000, dtype=np.uint32).reshape(3000, 3)
+    for vv, ff in ((v, f), (v2, f2)):
+        o = po.OracleSDF(vv, ff, True, R)
+        s = SDF(vv, ff)
+        s.set_raycast_axes(R)
+        p = rng.uniform(-1.2, 1.2, (150_000, 3)).astype(np.float32)
+        p[:2000] = vv[rng.integers(0, vv.shape[0], 2000)]  # on vertices: edge / vertex hits
+        assert (s.raycast_detail(p) == o.raycast_detail(p)).all()
+        assert (s.contains(p) == o.contains(p)).all()
+        assert same_float(s(p), o(p)).all()
+        for opt in (0, 1):  # strict and packet kernels share the grid
+            s.set_option("sort_queries", opt)
+            assert (s.contains(p[:20000]) == o.contains(p[:20000])).all()
+
+
 def test_degenerate_vertex_sets_use_deep_trees():
     """geometric vertex sequence -> very deep nanoflann tree -> global-memory stack variant"""
     rng = np.random.default_rng(2)
