@@ -9,12 +9,16 @@
 //              (tight child boxes + divlow/divhigh + child refs), kd_split 4 B / node
 //   kd_pts4    16 B / padded tree position, in tree (vind) order: a leaf is a contiguous run
 //   geo        64 B / face: a, b, c, unit normal, area (world frame) for dist_point2tri
+//   rface/fbox 48 + 24 B / face: a', b', c', n' and the AABB in the rotated ray-cast frame
+//   gr_*       column grid over (x', y') of that frame: cell -> faces whose AABB touches it
+//              (candidates of the z+/z- parity rays, one O(1) lookup per query)
 //   rnodes     32 B / node: threaded (stackless, pre-order + skip link) LBVH over the
-//              rotated-frame face AABBs; Morton codes -> LDS radix sort -> Karras hierarchy,
-//              refit on update()
-//   rface      48 B / face: a', b', c', n' in the rotated ray-cast frame
-// Kernels are one lane per query; the kd traversal keeps its stack in LDS
-// ([level][lane] layout, conflict free for any mix of per-lane depths).
+//              rotated-frame face AABBs (x+ tie-break ray); Morton codes -> LDS radix sort ->
+//              Karras hierarchy, refit on update()
+//   kd_qn      128 B / 4-wide node of the packet pass (two kd levels collapsed, leaf groups)
+// Two query kernels: k_query (one lane per query, exact nanoflann emulation, stack in LDS with
+// [level][lane] layout) and k_query_packet (one wave per 64 Morton-adjacent queries, the
+// dominant kernel).  DESIGN.md describes both and why their results are the reference's.
 
 #include <hip/hip_runtime.h>
 
@@ -258,48 +262,12 @@ __device__ __forceinline__ int kd_nearest(const MeshDev& M, float qx, float qy, 
 }
 
 // =========================================================================================
-// ray parity (Impl::_raycast, sdf.cpp:276-328) over the threaded LBVH.
+// ray parity (Impl::_raycast, sdf.cpp:276-328).
 // Result-relevant per face: closed-interval Overlap of the degenerate query
 // box with the face's rotated AABB (RTree.h:1427-1438) && facing test && bary2d >= 0.
-// The z+ and z- rays share (x,y), the facing dot product and bary2d, so they are one walk.
+// The z+ and z- rays share (x,y), the facing dot product and bary2d, so they are one pass over
+// the column grid's candidates; the x+ tie-break ray walks the threaded LBVH.
 // =========================================================================================
-__device__ __forceinline__ void ray_z_pair(const MeshDev& M, V3 q, int& zp, int& zm) {
-    zp = 0;
-    zm = 0;
-    uint32_t i = 0;
-    const uint32_t n = M.n_rnodes;
-    while (i < n) {
-        const float4 a = M.rnodes[2 * (size_t)i];
-        const float4 b = M.rnodes[2 * (size_t)i + 1];
-        const bool hit = !(q.x > a.z || a.x > q.x) && !(q.y > a.w || a.y > q.y);
-        const uint32_t skip = __float_as_uint(b.z), face = __float_as_uint(b.w);
-        if (!hit) {
-            i = skip;
-            continue;
-        }
-        if (face != NOFACE) {
-            const bool okp = !(q.z > b.y || b.x > FLT_MAX);   // box [q.z, FLT_MAX]
-            const bool okm = !(-FLT_MAX > b.y || b.x > q.z);  // box [-FLT_MAX, q.z]
-            const float4 f0 = M.rface[3 * (size_t)face];      // a'.xyz b'.x
-            const float4 f1 = M.rface[3 * (size_t)face + 1];  // b'.yz c'.xy
-            const float4 f2 = M.rface[3 * (size_t)face + 2];  // c'.z n'.xyz
-            const V3 nr = {f2.y, f2.z, f2.w};
-            const V3 dv = sdfk::sub(q, V3{f0.x, f0.y, f0.z});
-            const float s = sdfk::dot(nr, dv) * nr.z;  // sdf.cpp:301-302, ax_idx = 2
-            const bool pos = s > 0.f;                  // z- needs pos, z+ needs !pos
-            if (pos ? okm : okp) {
-                if (sdfk::bary2d_inside(q.x, q.y, f0.x, f0.y, f0.w, f1.x, f1.z, f1.w)) {
-                    if (pos)
-                        zm ^= 1;
-                    else
-                        zp ^= 1;
-                }
-            }
-        }
-        i = i + 1;
-    }
-}
-
 __device__ __forceinline__ int ray_x_pos(const MeshDev& M, V3 q) {
     int c = 0;
     uint32_t i = 0;
@@ -375,51 +343,6 @@ __device__ __forceinline__ void ray_z_pair_grid(const MeshDev& M, V3 q, int& zp,
     const uint32_t e = M.gr_start[c + 1];
     for (uint32_t k = M.gr_start[c]; k < e; ++k) ray_face_z(M, q, M.gr_items[k], zp, zm);
     for (uint32_t k = 0; k < M.gr_nbig; ++k) ray_face_z(M, q, M.gr_big[k], zp, zm);
-}
-
-// Wave-cooperative form of ray_z_pair for 64 Morton-adjacent queries: the threaded walk is
-// wave-uniform (a node is entered when ANY lane's point is inside its xy box; nodes and faces
-// come in by scalar loads) and each lane applies the exact per-face predicate to the leaves
-// whose box it is inside.  XOR parity is order independent and lanes only count faces that pass
-// their own Overlap test, so the result per lane equals ray_z_pair's.
-__device__ __forceinline__ void ray_z_pair_packet(const MeshDev& M, V3 q, bool active, int& zp, int& zm) {
-    zp = 0;
-    zm = 0;
-    uint32_t i = 0;
-    const uint32_t n = M.n_rnodes;
-    while (i < n) {
-        i = __builtin_amdgcn_readfirstlane(i);
-        const float4 a = M.rnodes[2 * (size_t)i];
-        const float4 b = M.rnodes[2 * (size_t)i + 1];
-        const bool hit = active && !(q.x > a.z || a.x > q.x) && !(q.y > a.w || a.y > q.y);
-        const uint32_t skip = __float_as_uint(b.z), face = __float_as_uint(b.w);
-        if (__ballot(hit) == 0ull) {
-            i = skip;
-            continue;
-        }
-        if (face != NOFACE) {
-            const float4 f0 = M.rface[3 * (size_t)face];      // a'.xyz b'.x
-            const float4 f1 = M.rface[3 * (size_t)face + 1];  // b'.yz c'.xy
-            const float4 f2 = M.rface[3 * (size_t)face + 2];  // c'.z n'.xyz
-            if (hit) {
-                const bool okp = !(q.z > b.y || b.x > FLT_MAX);
-                const bool okm = !(-FLT_MAX > b.y || b.x > q.z);
-                const V3 nr = {f2.y, f2.z, f2.w};
-                const V3 dv = sdfk::sub(q, V3{f0.x, f0.y, f0.z});
-                const float s = sdfk::dot(nr, dv) * nr.z;
-                const bool pos = s > 0.f;
-                if (pos ? okm : okp) {
-                    if (sdfk::bary2d_inside(q.x, q.y, f0.x, f0.y, f0.w, f1.x, f1.z, f1.w)) {
-                        if (pos)
-                            zm ^= 1;
-                        else
-                            zp ^= 1;
-                    }
-                }
-            }
-        }
-        i = i + 1;
-    }
 }
 
 // _raycast for a whole wave; lanes with valid == false take no part
