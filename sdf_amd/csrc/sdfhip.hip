@@ -102,6 +102,7 @@ struct MeshDev {
     const uint32_t* gr_items;   // face ids, cell by cell
     const uint32_t* gr_big;     // faces spanning too many cells: tested by every query
     uint32_t gr_nbig;
+    int ray_lbvh;  // packet kernel: walk the LBVH cooperatively instead of the grid (long lists)
     int gr_g;
     float gr_o0, gr_o1, gr_inv0, gr_inv1;
     float R[9];
@@ -345,6 +346,52 @@ __device__ __forceinline__ void ray_z_pair_grid(const MeshDev& M, V3 q, int& zp,
     for (uint32_t k = 0; k < M.gr_nbig; ++k) ray_face_z(M, q, M.gr_big[k], zp, zm);
 }
 
+// Wave-cooperative walk of the threaded LBVH for 64 Morton-adjacent queries (used instead of
+// the column grid when faces are large against the grid, i.e. the lists are long): the walk is
+// wave-uniform (a node is entered when ANY lane's point is inside its xy box; nodes and faces
+// come in by scalar loads) and each lane applies the exact per-face predicate to the leaves
+// whose box it is inside.  XOR parity is order independent and lanes only count faces that pass
+// their own Overlap test, so the result per lane equals ray_z_pair's.
+__device__ __forceinline__ void ray_z_pair_packet(const MeshDev& M, V3 q, bool active, int& zp, int& zm) {
+    zp = 0;
+    zm = 0;
+    uint32_t i = 0;
+    const uint32_t n = M.n_rnodes;
+    while (i < n) {
+        i = __builtin_amdgcn_readfirstlane(i);
+        const float4 a = M.rnodes[2 * (size_t)i];
+        const float4 b = M.rnodes[2 * (size_t)i + 1];
+        const bool hit = active && !(q.x > a.z || a.x > q.x) && !(q.y > a.w || a.y > q.y);
+        const uint32_t skip = __float_as_uint(b.z), face = __float_as_uint(b.w);
+        if (__ballot(hit) == 0ull) {
+            i = skip;
+            continue;
+        }
+        if (face != NOFACE) {
+            const float4 f0 = M.rface[3 * (size_t)face];      // a'.xyz b'.x
+            const float4 f1 = M.rface[3 * (size_t)face + 1];  // b'.yz c'.xy
+            const float4 f2 = M.rface[3 * (size_t)face + 2];  // c'.z n'.xyz
+            if (hit) {
+                const bool okp = !(q.z > b.y || b.x > FLT_MAX);
+                const bool okm = !(-FLT_MAX > b.y || b.x > q.z);
+                const V3 nr = {f2.y, f2.z, f2.w};
+                const V3 dv = sdfk::sub(q, V3{f0.x, f0.y, f0.z});
+                const float s = sdfk::dot(nr, dv) * nr.z;
+                const bool pos = s > 0.f;
+                if (pos ? okm : okp) {
+                    if (sdfk::bary2d_inside(q.x, q.y, f0.x, f0.y, f0.w, f1.x, f1.z, f1.w)) {
+                        if (pos)
+                            zm ^= 1;
+                        else
+                            zp ^= 1;
+                    }
+                }
+            }
+        }
+        i = i + 1;
+    }
+}
+
 // _raycast for a whole wave; lanes with valid == false take no part
 __device__ __forceinline__ float raycast_packet(const MeshDev& M, V3 p, bool valid) {
     const bool inbox = valid && !(p.x < M.bb[0] || p.x > M.bb[3] || p.y < M.bb[1] || p.y > M.bb[4] ||
@@ -352,7 +399,10 @@ __device__ __forceinline__ float raycast_packet(const MeshDev& M, V3 p, bool val
     if (__ballot(inbox) == 0ull) return -1.f;
     const V3 q = sdfk::mulR(p, M.R);
     int zp = 0, zm = 0;
-    if (inbox) ray_z_pair_grid(M, q, zp, zm);
+    if (M.ray_lbvh)
+        ray_z_pair_packet(M, q, inbox, zp, zm);
+    else if (inbox)
+        ray_z_pair_grid(M, q, zp, zm);
     int result = zp + zm;
     if (inbox && result == 1) result += ray_x_pos(M, q);  // tiebreaker (sdf.cpp:326), rare
     return (inbox && result > 1) ? 1.0f : -1.0f;
@@ -1518,6 +1568,8 @@ struct sdfhip_ctx {
     uint32_t* d_gr_s2 = nullptr;
     size_t gr_cells_cap = 0, gr_items_cap = 0;
     uint32_t gr_nbig = 0, gr_entries = 0;
+    bool gr_coarsened = false;
+    int64_t opt_ray_mode = 0;  // 0 automatic, 1 column grid, 2 cooperative LBVH (packet kernel)
     GridParams gr = {1, 0.f, 0.f, 0.f, 0.f};
     float* d_normals = nullptr;
     float* d_areas = nullptr;
@@ -1672,6 +1724,8 @@ int build_grid(sdfhip_ctx* h) {
     }
     int g = (int)std::sqrt((double)n);
     g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    const int g_first = g;
+    bool long_lists = false;  // > 10 cells per face at the natural resolution
     if (!h->d_gr_nbig) {
         if (int rc = dalloc(&h->d_gr_nbig, 1)) return rc;
         if (int rc = dalloc(&h->d_gr_big, n)) return rc;
@@ -1700,6 +1754,7 @@ int build_grid(sdfhip_ctx* h) {
         HIPC(hipMemcpyAsync(&total, h->d_gr_start + (cells - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPC(hipMemcpyAsync(&nbig, h->d_gr_nbig, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPC(hipStreamSynchronize(s));
+        if (g == g_first) long_lists = (size_t)total + 256 * (size_t)nbig > 10 * (size_t)n;
         // many faces much larger than a cell: a coarser grid keeps the lists (and memory) short
         if (((size_t)total > 16 * (size_t)n + 4096 || (size_t)nbig > (size_t)n / 64 + 16) && g > 1) {
             g = g / 2;
@@ -1715,8 +1770,11 @@ int build_grid(sdfhip_ctx* h) {
                                                            h->d_gr_big, h->d_gr_nbig);
         HIPC(hipGetLastError());
         h->gr = G;
+        h->gr_coarsened = long_lists;
         h->gr_nbig = nbig;
         h->gr_entries = total;
+        if (std::getenv("SDFHIP_DEBUG"))
+            std::fprintf(stderr, "[sdfhip] column grid g=%d (first %d) entries=%u big=%u faces=%u\n", g, g_first, total, nbig, n);
         return 0;
     }
 }
@@ -1863,6 +1921,10 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.gr_big = h->d_gr_big;
     M.gr_nbig = h->robust ? h->gr_nbig : 0;
     M.gr_g = h->gr.g;
+    // automatic: faces that touch > 10 cells each at the natural resolution are large against
+    // the cells and the per-lane lists are long; the wave-cooperative LBVH walk shares them
+    // among 64 lanes
+    M.ray_lbvh = h->opt_ray_mode == 2 || (h->opt_ray_mode == 0 && h->gr_coarsened) ? 1 : 0;
     M.gr_o0 = h->gr.o0, M.gr_o1 = h->gr.o1, M.gr_inv0 = h->gr.inv0, M.gr_inv1 = h->gr.inv1;
     for (int d = 0; d < 9; ++d) M.R[d] = h->R[d];
     return M;
@@ -2561,7 +2623,10 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_build_threads = v < 1 ? 1 : v;
     else if (!strcmp(key, "packet"))
         h->opt_packet = v;
-    else if (!strcmp(key, "host_chunk")) {
+    else if (!strcmp(key, "ray_mode")) {
+        if (v < 0 || v > 2) return fail(SDFHIP_E_INVALID, "ray_mode must be 0 (auto), 1 (grid) or 2 (LBVH)");
+        h->opt_ray_mode = v;
+    } else if (!strcmp(key, "host_chunk")) {
         if (v != 0 && (v < 1024 || v > (1ll << 27)))
             return fail(SDFHIP_E_INVALID, "host_chunk must be 0 (automatic) or in [1024, 2^27]");
         h->opt_host_chunk = v;

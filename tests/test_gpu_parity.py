@@ -148,6 +148,10 @@ def test_ray_grid_big_faces_and_coarsening():
         for opt in (0, 1):  # strict and packet kernels share the grid
             s.set_option("sort_queries", opt)
             assert (s.contains(p[:20000]) == o.contains(p[:20000])).all()
+        for mode in (1, 2, 0):  # packet kernel: column grid / cooperative LBVH walk / automatic
+            s.set_option("ray_mode", mode)
+            assert (s.contains(p) == o.contains(p)).all()
+            assert same_float(s(p[:50000]), o(p[:50000])).all()
 
 
 def test_degenerate_vertex_sets_use_deep_trees():

@@ -13,10 +13,21 @@ ap.add_argument("--grid", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--robust", type=int, default=1)
 ap.add_argument("--only", default="")
+ap.add_argument("--mesh", default="torus", help="torus | ico<subdiv> (radius 0.8, 5%% radial noise) | teapot")
 ap.add_argument("--nosort", type=int, default=0)
+ap.add_argument("--ray-mode", type=int, default=0)
+ap.add_argument("--noise", type=float, default=0.05)
 ap.add_argument("--group", type=int, default=0, help="packet_group option (0 = library default)")
 a = ap.parse_args()
-v, f = meshes.torus(a.res, a.res)
+if a.mesh.startswith("ico"):
+    v, f = meshes.icosphere(int(a.mesh[3:]), radius=0.8, noise=a.noise, seed=3)
+elif a.mesh == "teapot":
+    import numpy as _np
+    g = _np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "golden_teapot.npz"))
+    v, f = g["verts"], g["faces"]
+else:
+    v, f = meshes.torus(a.res, a.res)
+print("mesh", a.mesh, v.shape, f.shape)
 s = sdf_amd.SDF(v, f, robust=bool(a.robust))
 if a.group:
     s.set_option("packet_group", a.group)
@@ -30,6 +41,8 @@ else:
     g = torch.Generator(device=dev).manual_seed(7)
     pts = torch.rand((a.n, 3), device=dev, generator=g).mul_(2).sub_(1)
 n = pts.shape[0]
+if a.ray_mode:
+    s.set_option("ray_mode", a.ray_mode)
 if a.nosort:
     s.set_option("sort_queries", 0)
 print("stats", s.stats)
