@@ -1849,9 +1849,12 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
             }
         }
     });
+    auto tq0 = std::chrono::steady_clock::now();
     h->kd.build_quads();
     fill.get();
+    auto tq1 = std::chrono::steady_clock::now();
     const int rc_dev = dev_side.get();
+    auto tq2 = std::chrono::steady_clock::now();
     if (rc_dev) return fail(rc_dev, "%s", dev_err.empty() ? "device-side update failed" : dev_err.c_str());
     if (h->kd.nodes.size() >= (size_t)KD_MARK) return fail(SDFHIP_E_INVALID, "kd-tree too large");
     if (h->kd.quads.size() > h->kd_quads_cap) {
@@ -1894,6 +1897,12 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     HIPC(hipStreamSynchronize(s));  // host arrays are pageable and rebuilt by the next update
     h->last_update_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (std::getenv("SDFHIP_DEBUG")) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[sdfhip] update %.2f ms: pre %.2f kd %.2f quads+fill %.2f wait-device %.2f upload %.2f\n",
+                     h->last_update_ms, ms(t0, tk), h->last_kd_ms, ms(tq0, tq1), ms(tq1, tq2),
+                     ms(tq2, std::chrono::steady_clock::now()));
+    }
     return 0;
 }
 

@@ -49,9 +49,19 @@ int main() {
     std::mt19937 rg(5);
     std::uniform_real_distribution<float> U(-1, 1);
     for (int n : {7, 11, 500, 25000, 180000}) {
-        for (int mode = 0; mode < 2; ++mode) {
+        for (int mode = 0; mode < 6; ++mode) {
             std::vector<float> p(3 * (size_t)n);
-            for (auto& x : p) x = mode ? (float)(int)(U(rg) * 6) * 0.25f : U(rg);  // lattice: many equal keys
+            for (auto& x : p) x = mode == 1 ? (float)(int)(U(rg) * 6) * 0.25f : U(rg);  // 1: lattice, many equal keys
+            if (mode == 2)  // all points equal
+                for (auto& x : p) x = 0.5f;
+            if (mode == 3)  // sorted along x, two values of y
+                for (int i = 0; i < n; ++i) p[3 * i] = (float)i / n, p[3 * i + 1] = (i & 1) ? 0.f : -0.f;
+            if (mode == 4)  // reverse sorted along z, x and y constant
+                for (int i = 0; i < n; ++i) p[3 * i] = 1.f, p[3 * i + 1] = 2.f, p[3 * i + 2] = (float)(n - i);
+            if (mode == 5)  // two tight clusters and a few strays
+                for (int i = 0; i < n; ++i)
+                    for (int d = 0; d < 3; ++d)
+                        p[3 * i + d] = (i % 97 == 0) ? U(rg) * 50 : ((i & 1) ? 10.f : -10.f) + U(rg) * 1e-3f;
             for (uint32_t g : {10u, 16u, 32u, 60u}) {
                 sdfk::KdHost a, b;
                 a.group_max = b.group_max = g;
