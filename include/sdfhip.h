@@ -150,7 +150,9 @@ int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* out);
 
 /* Tuning knobs (no counterpart). key: "sort_queries" (0/1, default 1: Morton-sort query
  * chunks of >= sort_min points), "sort_min", "chunk" (points per internal chunk), "packet" (0: strict kernel only),
- * "packet_group" (vertices per leaf group of the packet pass, 10..60, applies at the next update), "host_chunk" (points per
+ * "fast_nn" (0/1, applies at the next update: the vertex tree is built on the GPU, no host kd-tree;
+ * distances stay exact, an exact fp32 distance tie goes to the lowest (Morton code, index) vertex instead of the
+ * reference's first-visited one), "packet_group" (vertices per leaf group of the packet pass, 10..60, applies at the next update), "host_chunk" (points per
  * staging slot of the host entry points, 0 = automatic),
  * "build_threads" (host threads of the kd-tree build; default min(cores, OMP_NUM_THREADS, 16)), "profile" (1: time every query kernel launch
  * with hipEvents on its stream, read back through sdfhip_get_stats; 2: same and reset). */

@@ -362,7 +362,11 @@ inline uint32_t KdHost::quad_of(uint32_t ref, int level) {
     KdQuadH q;
     for (int k = 0; k < 4; ++k) {
         for (int d = 0; d < 3; ++d) q.box[k][d] = inf, q.box[k][3 + d] = -inf;
-        q.ref[k] = 0;
+        // an unused slot is an EMPTY GROUP, never a quad index: its lower bound is +inf, which
+        // still passes `lb <= best * c` while best * c overflows (first descent; queries so far
+        // away that every distance is +inf), and a stale index 0 would send the walk back to the
+        // root for ever
+        q.ref[k] = KD_LEAF_BIT;
         q.pad[k] = 0;
     }
     const KdNodeH nd = nodes[ref];

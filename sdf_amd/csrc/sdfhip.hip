@@ -82,6 +82,7 @@ struct MeshDev {
     const uint32_t* kd_split;
     const float4* kd_qn;  // 4-wide collapse for the packet pass: 128 B {box[4][6], ref[4], pad}
     uint32_t kd_qroot;
+    int fast;  // "fast_nn": GPU-built tree, exact distances, ties go to the lowest tree position
     const int32_t* kd_vind;
     uint32_t kd_root;
     float bb[6];  // mesh AABB == kd root bbox
@@ -742,7 +743,9 @@ __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float 
                             // two part above that group
                             const uint32_t hp = (h & KD_LEAF) ? (((h & sdfk::KD_REF_MASK) >> 4) << 2) : h;
                             // (a group ref in h always names an earlier group: h0 predates this one)
-                            if ((uint32_t)kd_dfs_first(M, qx, qy, qz, (int)hp, (int)idx) == idx) h = idx;
+                            const bool idx_first =
+                                M.fast ? idx < hp : (uint32_t)kd_dfs_first(M, qx, qy, qz, (int)hp, (int)idx) == idx;
+                            if (idx_first) h = idx;
                         }
                         s2 = min(s2, max(du, b));
                         if (du < b) {
@@ -863,14 +866,16 @@ __global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float*
     //  (3) else defer to the strict kernel (exact emulation).
     const int pos = packet_resolve(M, p.x, p.y, p.z, pb.b, pb.h);
     bool amb = false;
-    if (valid && (!(pb.s > pb.b * M.amb_c) || !(pb.b >= 1e-30f))) {
-        amb = true;
-        if (pos >= 0 && pb.b < FLT_MAX) {
-            const float mb = kd_path_max_bound(M, p.x, p.y, p.z, pos);
-            amb = !(mb <= pb.s);
+    if (!M.fast) {
+        if (valid && (!(pb.s > pb.b * M.amb_c) || !(pb.b >= 1e-30f))) {
+            amb = true;
+            if (pos >= 0 && pb.b < FLT_MAX) {
+                const float mb = kd_path_max_bound(M, p.x, p.y, p.z, pos);
+                amb = !(mb <= pb.s);
+            }
         }
+        if (pos < 0) amb = true;
     }
-    if (pos < 0) amb = true;
     {   // ambiguous lanes of this wave, in sorted order: compacted (stably) by k_fb_compact so
         // that the strict fallback kernel still sees Morton-coherent waves
         const unsigned long long m = __ballot(valid && amb);
@@ -881,7 +886,7 @@ __global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float*
     }
     if (!valid || amb) return;
     if (KIND == Q_NN) {
-        ((int32_t*)out)[src] = M.kd_vind[pos];
+        ((int32_t*)out)[src] = pos >= 0 ? M.kd_vind[pos] : -1;  // (-1: fast mode, no finite distance)
     } else {
         const bool trunc = (KIND == Q_CONTAINS) ? true : (trunc_aabb != 0);
         const float v = calc_tail<ROBUST>(M, p, trunc, sign, pos);
@@ -1461,6 +1466,89 @@ __global__ void k_lbvh_leaf_boxes(int n, const uint32_t* __restrict__ posL,
     rnodes[2 * (size_t)pos + 1] = w;
 }
 
+// =========================================================================================
+// "fast_nn" mode: the vertex tree of the packet pass built entirely on the GPU (no host kd-tree).
+// Vertices are sorted by 30-bit Morton code; 16 consecutive ones form a packet group; an implicit
+// 4-ary tree of quad nodes is reduced bottom-up over the groups.  Distances and the minimum are
+// exact; what differs from the reference is the winner of an exact fp32 distance tie: the lowest
+// tree position (Morton order, equal codes by vertex index) instead of nanoflann's first-visited.
+// =========================================================================================
+__global__ void k_vtx_morton(const float* __restrict__ verts, uint32_t nv, Bounds B,
+                             uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    keys[i] = morton30(verts[3 * (size_t)i], verts[3 * (size_t)i + 1], verts[3 * (size_t)i + 2], B.lo, B.inv);
+}
+__global__ void k_fast_positions(const float* __restrict__ verts, const uint32_t* __restrict__ sorted_idx,
+                                 uint32_t nv, uint32_t nalloc, float4* __restrict__ pts4,
+                                 int32_t* __restrict__ vind) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nalloc) return;
+    if (i < nv) {
+        const uint32_t v = sorted_idx[i];
+        pts4[i] = make_float4(verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2], 3.0e38f);
+        vind[i] = (int32_t)v;
+    } else {
+        pts4[i] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f);
+        vind[i] = -1;
+    }
+}
+constexpr uint32_t FAST_GROUP = 16;  // vertices per packet group (4 chunks)
+__device__ __forceinline__ void quad_store(float4* q, int k, const float* lo, const float* hi, uint32_t ref,
+                                           float* flat) {
+    (void)q;
+    for (int d = 0; d < 3; ++d) flat[6 * k + d] = lo[d], flat[6 * k + 3 + d] = hi[d];
+    flat[24 + k] = __uint_as_float(ref);
+    flat[28 + k] = 0.f;
+}
+__global__ void k_fast_quads_leaf(const float4* __restrict__ pts4, uint32_t nv, uint32_t ngroups,
+                                  uint32_t nq, float4* __restrict__ out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float flat[32];
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t g = 4 * q + k;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t ref = KD_LEAF;  // unused slot: empty group (see kd_host.h quad_of)
+        if (g < ngroups) {
+            const uint32_t first = FAST_GROUP * g;
+            const uint32_t cnt = nv - first < FAST_GROUP ? nv - first : FAST_GROUP;
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const float4 p = pts4[first + j];
+                lo[0] = fminf(lo[0], p.x), lo[1] = fminf(lo[1], p.y), lo[2] = fminf(lo[2], p.z);
+                hi[0] = fmaxf(hi[0], p.x), hi[1] = fmaxf(hi[1], p.y), hi[2] = fmaxf(hi[2], p.z);
+            }
+            ref = KD_LEAF | ((first >> 2) << 4) | ((cnt + 3u) >> 2);
+        }
+        quad_store(nullptr, k, lo, hi, ref, flat);
+    }
+    for (int j = 0; j < 8; ++j)
+        out[8 * (size_t)q + j] = make_float4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
+}
+__global__ void k_fast_quads_inner(const float4* __restrict__ child, uint32_t nchild, uint32_t child_off,
+                                   uint32_t nq, float4* __restrict__ out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float flat[32];
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t c = 4 * q + k;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t ref = KD_LEAF;
+        if (c < nchild) {
+            const float* cf = (const float*)(child + 8 * (size_t)c);
+            for (int j = 0; j < 4; ++j)
+                for (int d = 0; d < 3; ++d) {
+                    lo[d] = fminf(lo[d], cf[6 * j + d]);
+                    hi[d] = fmaxf(hi[d], cf[6 * j + 3 + d]);
+                }
+            ref = child_off + c;
+        }
+        quad_store(nullptr, k, lo, hi, ref, flat);
+    }
+    for (int j = 0; j < 8; ++j)
+        out[8 * (size_t)q + j] = make_float4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
+}
+
 // column grid build: count (or fill) the cells each face's rotated AABB touches
 struct GridParams {
     int g;
@@ -1569,6 +1657,13 @@ struct sdfhip_ctx {
     size_t gr_cells_cap = 0, gr_items_cap = 0;
     uint32_t gr_nbig = 0, gr_entries = 0;
     bool gr_coarsened = false;
+    // fast_nn mode (GPU-built vertex tree)
+    int64_t opt_fast_nn = 0;   // applies at the next update
+    bool fast_active = false;  // what the structures on the device currently are
+    uint32_t fast_qroot = KD_LEAF, fast_levels = 1, fast_quads = 0;
+    uint32_t* d_vkeys = nullptr;
+    uint32_t* d_vidx = nullptr;
+    size_t vkeys_cap = 0;
     int64_t opt_ray_mode = 0;  // 0 automatic, 1 column grid, 2 cooperative LBVH (packet kernel)
     GridParams gr = {1, 0.f, 0.f, 0.f, 0.f};
     float* d_normals = nullptr;
@@ -1801,6 +1896,66 @@ int update_device_side(sdfhip_ctx* h) {
     return 0;
 }
 
+// fast_nn: vertex tree of the packet pass built on the device (d_verts and aabb are current)
+int build_fast_tree(sdfhip_ctx* h) {
+    hipStream_t s = h->stream;
+    const uint32_t nv = h->nv;
+    const uint32_t ngroups = (nv + FAST_GROUP - 1) / FAST_GROUP;
+    const size_t nalloc = (size_t)FAST_GROUP * ngroups + 16;
+    // level sizes of the implicit 4-ary tree over the groups, leaves first; the root is last
+    uint32_t level_n[20];
+    uint32_t levels = 0, total = 0;
+    for (uint32_t c = ngroups; levels == 0 || c > 1;) {
+        c = (c + 3) / 4;
+        if (c == 0) c = 1;
+        level_n[levels++] = c;
+        total += c;
+        if (c == 1) break;
+    }
+    if (total > h->kd_quads_cap) {
+        if (int rc = dalloc(&h->d_kd_qn, 8 * (size_t)total)) return rc;
+        h->kd_quads_cap = total;
+    }
+    if (nalloc > h->kd_pos_cap) {
+        if (int rc = dalloc(&h->d_kd_pts4, nalloc)) return rc;
+        if (int rc = dalloc(&h->d_kd_vind, nalloc)) return rc;
+        h->kd_pos_cap = nalloc;
+    }
+    if ((size_t)nv > h->vkeys_cap) {
+        if (int rc = dalloc(&h->d_vkeys, (size_t)nv)) return rc;
+        if (int rc = dalloc(&h->d_vidx, (size_t)nv)) return rc;
+        h->vkeys_cap = nv;
+    }
+    Bounds B;
+    for (int d = 0; d < 3; ++d) {
+        B.lo[d] = h->aabb[d];
+        const float ext = h->aabb[3 + d] - h->aabb[d];
+        B.inv[d] = (ext > 0.f && ext < FLT_MAX) ? 1024.f / ext : 0.f;
+    }
+    uint32_t* sorted_idx = h->d_vidx;
+    if (nv) {
+        k_vtx_morton<<<(nv + 255) / 256, 256, 0, s>>>(h->d_verts, nv, B, h->d_vkeys);
+        if (int rc = h->sorter.sort(h->d_vkeys, h->d_vidx, nv, 30, 1, s, nullptr, &sorted_idx)) return rc;
+    }
+    k_fast_positions<<<(uint32_t)((nalloc + 255) / 256), 256, 0, s>>>(h->d_verts, sorted_idx, nv,
+                                                                      (uint32_t)nalloc, h->d_kd_pts4,
+                                                                      h->d_kd_vind);
+    k_fast_quads_leaf<<<(level_n[0] + 63) / 64, 64, 0, s>>>(h->d_kd_pts4, nv, ngroups, level_n[0], h->d_kd_qn);
+    uint32_t child_off = 0;
+    for (uint32_t l = 1; l < levels; ++l) {
+        const uint32_t off = child_off + level_n[l - 1];
+        k_fast_quads_inner<<<(level_n[l] + 63) / 64, 64, 0, s>>>(h->d_kd_qn + 8 * (size_t)child_off,
+                                                                 level_n[l - 1], child_off, level_n[l],
+                                                                 h->d_kd_qn + 8 * (size_t)off);
+        child_off = off;
+    }
+    HIPC(hipGetLastError());
+    h->fast_qroot = total - 1;
+    h->fast_levels = levels;
+    h->fast_quads = total;
+    return 0;
+}
+
 int do_update(sdfhip_ctx* h, bool draw_R) {
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = h->stream;
@@ -1822,6 +1977,19 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     if (h->nv)
         HIPC(hipMemcpyAsync(h->d_verts, h->h_verts, sizeof(float) * 3 * (size_t)h->nv,
                             hipMemcpyHostToDevice, s));
+    if (h->opt_fast_nn) {
+        // no host kd-tree: everything is built on the device, on one stream
+        h->last_kd_ms = 0.f;
+        if (int rc = update_device_side(h)) return rc;
+        if (int rc = build_fast_tree(h)) return rc;
+        h->amb_c = 1.f, h->amb_c2 = 1.f;  // exact minimum; nothing is deferred in this mode
+        HIPC(hipStreamSynchronize(s));
+        h->fast_active = true;
+        h->last_update_ms =
+            std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    }
+    h->fast_active = false;
     std::string dev_err;
     auto dev_side = std::async(std::launch::async, [h, &dev_err]() -> int {
         if (hipSetDevice(h->device) != hipSuccess) return SDFHIP_E_HIP;
@@ -1911,9 +2079,10 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.kd_pn = h->d_kd_pn;
     M.kd_split = h->d_kd_split;
     M.kd_qn = h->d_kd_qn;
-    M.kd_qroot = h->kd.quad_root;
+    M.kd_qroot = h->fast_active ? h->fast_qroot : h->kd.quad_root;
+    M.fast = h->fast_active ? 1 : 0;
     M.kd_vind = h->d_kd_vind;
-    M.kd_root = h->kd.root_ref;
+    M.kd_root = h->fast_active ? KD_LEAF : h->kd.root_ref;
     for (int d = 0; d < 6; ++d) M.bb[d] = h->aabb[d];
     M.kd_pts4 = h->d_kd_pts4;
     M.amb_c = h->amb_c;
@@ -2026,10 +2195,13 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     const int64_t chunk = h->opt_chunk > 0 ? h->opt_chunk : (1 << 24);
     const bool sort_any = h->opt_sort && n >= h->opt_sort_min;
     // packet stack: <= 3 deferred slots per 4-wide level (+ the transient 4th); 132 B per slot
-    const uint32_t pstack = 3u * (uint32_t)(h->kd.quad_depth > 0 ? h->kd.quad_depth : 1) + 4u;
-    const bool packet_any = sort_any && KIND != Q_DETAIL && h->opt_packet && pstack * 132u <= 48u * 1024u;
-    const int64_t fb_cap = packet_any ? (n < (1ll << 27) ? n : (1ll << 27)) : 0;
-    if (sort_any)
+    const bool fast = h->fast_active;  // GPU-built tree: the packet kernel is the only nn search
+    const int qdepth = fast ? (int)h->fast_levels : h->kd.quad_depth;
+    const uint32_t pstack = 3u * (uint32_t)(qdepth > 0 ? qdepth : 1) + 4u;
+    const bool packet_any =
+        KIND != Q_DETAIL && (fast || (sort_any && h->opt_packet && pstack * 132u <= 48u * 1024u));
+    const int64_t fb_cap = packet_any && !fast ? (n < (1ll << 27) ? n : (1ll << 27)) : 0;
+    if (sort_any || fast)
         if (int rc = reserve_query_ws(h, n < chunk ? n : chunk, fb_cap)) return rc;
     int64_t deferred_pts = 0;  // points whose near ties may sit in the deferred list
     int flip = 0;              // d_fb_count[flip] holds the current list length
@@ -2063,8 +2235,8 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
                 return rc;
             perm = sorted_perm;
         }
-        if (perm && packet_any) {
-            if (deferred_pts + m > h->fb_cap)
+        if (packet_any && (perm || fast)) {
+            if (!fast && deferred_pts + m > h->fb_cap)
                 if (int rc = flush()) return rc;
             const size_t lds = (size_t)(PBLOCK / 64) * pstack * 33u * sizeof(uint32_t);
             constexpr int PK = KIND == Q_DETAIL ? Q_NN : KIND;
@@ -2073,6 +2245,10 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             k_query_packet<PK, ROBUST><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, lds, s>>>(
                 M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, pstack);
             if (int rc = prof.end(m)) return rc;
+            if (fast) {  // nothing is ever deferred
+                HIPC(hipGetLastError());
+                continue;
+            }
             exclusive_scan_u32(h->d_amb_cnt, (uint32_t)((m + 63) / 64), h->d_amb_s1, h->d_amb_s2, s);
             k_fb_compact<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(
                 h->d_amb_mask, h->d_amb_cnt, perm, m, (uint32_t)off, h->d_fb_list, h->d_fb_count + flip,
@@ -2418,7 +2594,8 @@ void sdfhip_destroy(sdfhip_t* h) {
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
                     h->topo.depthI, h->d_qkeys, h->d_qperm, h->d_qbounds, h->d_gstack, h->d_kd_pts4,
-                    h->d_fb_list, h->d_fb_count, h->d_amb_mask, h->d_amb_cnt, h->d_amb_s1, h->d_amb_s2};
+                    h->d_fb_list, h->d_fb_count, h->d_amb_mask, h->d_amb_cnt, h->d_amb_s1, h->d_amb_s2,
+                    h->d_vkeys, h->d_vidx};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->sorter.release();
@@ -2562,8 +2739,8 @@ int sdfhip_adj_faces(const sdfhip_t* h, uint32_t v, const int32_t** ids) {
 }
 int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* o) {
     if (!h || !o) return fail(SDFHIP_E_INVALID, "null handle/out");
-    o->kd_nodes = (int32_t)h->kd.nodes.size();
-    o->kd_depth = h->kd.depth;
+    o->kd_nodes = h->fast_active ? (int32_t)h->fast_quads : (int32_t)h->kd.nodes.size();
+    o->kd_depth = h->fast_active ? (int32_t)h->fast_levels : h->kd.depth;
     o->bvh_nodes = h->robust ? (int32_t)h->n_rnodes : 0;
     o->bvh_depth = (int32_t)h->bvh_depth;
     o->last_update_ms = h->last_update_ms;
@@ -2632,6 +2809,8 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_build_threads = v < 1 ? 1 : v;
     else if (!strcmp(key, "packet"))
         h->opt_packet = v;
+    else if (!strcmp(key, "fast_nn"))
+        h->opt_fast_nn = v ? 1 : 0;  // takes effect at the next sdfhip_update
     else if (!strcmp(key, "ray_mode")) {
         if (v < 0 || v > 2) return fail(SDFHIP_E_INVALID, "ray_mode must be 0 (auto), 1 (grid) or 2 (LBVH)");
         h->opt_ray_mode = v;

@@ -7,10 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sdf_amd
 from sdf_amd import meshes
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=20); ap.add_argument("--res", type=int, default=424)
-ap.add_argument("--device-verts", type=int, default=0)
+ap.add_argument("--device-verts", type=int, default=0); ap.add_argument("--fast-nn", type=int, default=0)
 a = ap.parse_args()
 v0, f = meshes.torus(a.res, a.res)
 s = sdf_amd.SDF(v0, f, robust=True, copy=True)
+if a.fast_nn:
+    s.set_option("fast_nn", 1)
 dev = torch.device("cuda", 0)
 pts = torch.rand((4_000_000, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(7)).mul_(2).sub_(1)
 tv0 = torch.from_numpy(v0).to(dev)
