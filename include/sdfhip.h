@@ -23,6 +23,7 @@
 #ifndef SDFHIP_H_
 #define SDFHIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -147,6 +148,14 @@ typedef struct {
     int64_t last_fallback_points;
 } sdfhip_stats_t;
 int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* out);
+
+/* Page-locked host memory for the host-pointer entry points (no counterpart: the reference's
+ * Eigen / numpy arrays are pageable).  Points read from, and results written to, such memory move
+ * by DMA at the full PCIe rate and without blocking the calling thread; pageable memory works
+ * everywhere too.  (Page-locking the caller's own buffers per call, hipHostRegister, was tried and
+ * is refused for numpy-owned memory on the target boxes.) */
+int sdfhip_host_alloc(size_t bytes, void** out);
+int sdfhip_host_free(void* p);
 
 /* Tuning knobs (no counterpart). key: "sort_queries" (0/1, default 1: Morton-sort query
  * chunks of >= sort_min points), "sort_min", "chunk" (points per internal chunk), "packet" (0: strict kernel only),

@@ -2796,6 +2796,22 @@ int sdfhip_sample_surface(sdfhip_t* h, int64_t n, uint64_t seed, float* out) {
     (void)hipFree(d);
     return rc;
 }
+int sdfhip_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(SDFHIP_E_INVALID, "out is null");
+    *out = nullptr;
+    if (bytes == 0) bytes = 1;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return fail(SDFHIP_E_NOMEM, "hipHostMalloc of %zu bytes failed", bytes);
+    }
+    return 0;
+}
+int sdfhip_host_free(void* p) {
+    if (!p) return 0;
+    if (hipHostFree(p) != hipSuccess) return fail(SDFHIP_E_HIP, "hipHostFree failed");
+    return 0;
+}
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
     if (!h || !key) return fail(SDFHIP_E_INVALID, "null handle/key");
     std::lock_guard<std::mutex> lk(h->mu);

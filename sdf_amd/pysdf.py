@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "libsdfhip.so")
+_LIBPATH = os.environ.get("SDFHIP_LIB") or os.path.join(_HERE, "libsdfhip.so")  # SDFHIP_LIB: A/B builds while tuning
 
 # pybind.cpp:12 / 195
 num_threads = min(os.cpu_count() or 1, 32)
@@ -55,6 +55,7 @@ ABI_SYMBOLS = [
     "sdfhip_face_normals", "sdfhip_aabb", "sdfhip_adj_faces", "sdfhip_get_stats",
     "sdfhip_set_option", "sdfhip_last_error", "sdfhip_version",
     "sdfhip_sample_surface", "sdfhip_sample_surface_device",
+    "sdfhip_host_alloc", "sdfhip_host_free",
 ]
 
 
@@ -115,6 +116,8 @@ def load_library():
     L.sdfhip_sample_surface_device.argtypes = [vp, C.c_int64, C.c_uint64, vp, vp]
     L.sdfhip_get_stats.argtypes = [vp, C.POINTER(_Stats)]
     L.sdfhip_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.sdfhip_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.sdfhip_host_free.argtypes = [C.c_void_p]
     L.sdfhip_last_error.restype = C.c_char_p
     L.sdfhip_version.restype = C.c_char_p
     _lib = L
@@ -124,6 +127,35 @@ def load_library():
 def _check(rc):
     if rc != 0:
         raise SdfHipError(f"sdfhip error {rc}: {load_library().sdfhip_last_error().decode()}")
+
+
+class _PinnedBlock:
+    """owner of one sdfhip_host_alloc block; numpy arrays made from it keep it alive"""
+
+    def __init__(self, nbytes):
+        self._L = load_library()
+        self.ptr = C.c_void_p()
+        _check(self._L.sdfhip_host_alloc(max(1, int(nbytes)), C.byref(self.ptr)))
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        p = getattr(self, "ptr", None)
+        if p:
+            self._L.sdfhip_host_free(p)
+            self.ptr = None
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """numpy array in page-locked host memory (sdfhip_host_alloc): points kept in such arrays, and
+    results written into them through `out=`, cross PCIe by DMA at the full rate (no counterpart
+    in pysdf, whose arrays are pageable; plain numpy arrays work everywhere too)."""
+    dt = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    blk = _PinnedBlock(n)
+    buf = (C.c_char * max(1, n)).from_address(blk.ptr.value)
+    buf._sdfhip_owner = blk  # the ctypes buffer is the array's base: the block lives as long
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
 
 
 def _is_torch(x):
@@ -177,7 +209,7 @@ class SDF:
             self._h = None
 
     # ---- queries -----------------------------------------------------------------------
-    def _query(self, kind, points, trunc_aabb=False):
+    def _query(self, kind, points, trunc_aabb=False, out=None):
         L = self._L
         if _is_torch(points):
             import torch
@@ -206,34 +238,37 @@ class SDF:
             points = t.detach().cpu().numpy()
         p = _as_points(points)
         n = p.shape[0]
+        odt = {"sdf": np.float32, "contains": np.bool_, "nn": np.int32}[kind]
+        if out is None:
+            out = np.empty(n, dtype=odt)
+        elif not (isinstance(out, np.ndarray) and out.dtype == odt and out.shape == (n,)
+                  and out.flags.c_contiguous and out.flags.writeable):
+            raise TypeError(f"out must be a writable C-contiguous numpy array of shape ({n},) and dtype {np.dtype(odt)}")
         if kind == "sdf":
-            out = np.empty(n, dtype=np.float32)
             _check(L.sdfhip_sdf(self._h, p.ctypes.data_as(_fp), n, int(trunc_aabb),
                                 out.ctypes.data_as(_fp)))
-            return out
-        if kind == "contains":
-            out = np.empty(n, dtype=np.uint8)
+        elif kind == "contains":
             _check(L.sdfhip_contains(self._h, p.ctypes.data_as(_fp), n, out.ctypes.data_as(_bp)))
-            return out.view(np.bool_)
-        out = np.empty(n, dtype=np.int32)
-        _check(L.sdfhip_nn(self._h, p.ctypes.data_as(_fp), n, out.ctypes.data_as(_ip)))
+        else:
+            _check(L.sdfhip_nn(self._h, p.ctypes.data_as(_fp), n, out.ctypes.data_as(_ip)))
         return out
 
-    def __call__(self, points, trunc_aabb=False, n_threads=num_threads):
-        """Compute SDF on points (positive iff inside)."""
-        return self._query("sdf", points, trunc_aabb)
+    def __call__(self, points, trunc_aabb=False, n_threads=num_threads, *, out=None):
+        """Compute SDF on points (positive iff inside).  `out` (numpy inputs only, no counterpart
+        in pysdf): result array to fill instead of allocating one."""
+        return self._query("sdf", points, trunc_aabb, out)
 
-    def calc(self, points, trunc_aabb=False, n_threads=num_threads):
+    def calc(self, points, trunc_aabb=False, n_threads=num_threads, *, out=None):
         """Compute SDF on points (positive iff inside), alias of __call__."""
-        return self._query("sdf", points, trunc_aabb)
+        return self._query("sdf", points, trunc_aabb, out)
 
-    def contains(self, points, n_threads=num_threads):
+    def contains(self, points, n_threads=num_threads, *, out=None):
         """Test if points are in mesh."""
-        return self._query("contains", points)
+        return self._query("contains", points, out=out)
 
-    def nn(self, points, n_threads=num_threads):
+    def nn(self, points, n_threads=num_threads, *, out=None):
         """Find nearest neighbor indices."""
-        return self._query("nn", points)
+        return self._query("nn", points, out=out)
 
     def update(self):
         """Update the SDF to reflect any changes in verts."""

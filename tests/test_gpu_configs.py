@@ -147,3 +147,25 @@ def test_config4_full_shard_device_resident_properties():
     assert same_float(d[k].cpu().numpy(), o(hp)).all()
     assert (c[k].cpu().numpy() == o.contains(hp)).all()
     assert (nn[k].cpu().numpy() == o.nn(hp)).all()
+
+
+def test_page_locked_host_arrays_and_out_argument():
+    """host entry points on page-locked memory (sdfhip_host_alloc) and with a caller-provided
+    result array: same bits as the default"""
+    from sdf_amd import pinned_empty
+    v, f = meshes.torus(83, 83)
+    R = meshes.random_rotation(2)
+    s = SDF(v, f)
+    s.set_raycast_axes(R)
+    n = 1_500_000
+    pts = np.random.default_rng(5).uniform(-1, 1, (n, 3)).astype(np.float32)
+    d, c, k = s(pts), s.contains(pts), s.nn(pts)
+    pp = pinned_empty((n, 3), np.float32)
+    pp[:] = pts
+    od, oc, ok = pinned_empty(n, np.float32), pinned_empty(n, np.bool_), pinned_empty(n, np.int32)
+    assert s(pp, out=od) is od and same_float(od, d).all()
+    assert (s.contains(pp, out=oc) == c).all() and (s.nn(pp, out=ok) == k).all()
+    with pytest.raises(TypeError):
+        s(pts, out=np.empty(n, np.float64))
+    o = po.OracleSDF(v, f, True, R)
+    assert same_float(od[:100000], o(pts[:100000])).all()
