@@ -149,6 +149,56 @@ typedef struct {
 } sdfhip_stats_t;
 int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* out);
 
+/* ---------------------------------------------------------------------------------------------
+ * sdf::Renderer (sdf.hpp:282-369, src/renderer.cpp): image-space raycaster over the mesh seen by a
+ * pinhole camera at the origin facing +z.  Points are row-major float32 [N,2] image coordinates
+ * (x, y); images are row-major [height, width], pixel (r, c) = the point ((float)c, (float)r)
+ * (renderer.cpp:187-189).  Same conventions as above (0 / negative codes, caller-owned buffers).
+ * Results equal the reference's except for one documented rule: when two different vertices of
+ * exactly equal z compete for a pixel's vertex id, the reference keeps the one its R-tree meets
+ * first; here the lowest face id wins (order independent). */
+typedef struct sdfhip_renderer sdfhip_renderer_t;
+
+/* Replaces Renderer::Renderer(verts, faces, width, height, fx, fy, cx, cy, copy) (sdf.hpp:298-301,
+ * renderer.cpp:256-269) + Impl::Impl (renderer.cpp:20-31).  copy as in sdfhip_create. */
+int sdfhip_renderer_create(const float* verts, uint32_t n_verts, const uint32_t* faces, uint32_t n_faces,
+                           int width, int height, float fx, float fy, float cx, float cy, int copy,
+                           int device, sdfhip_renderer_t** out);
+/* Replaces Renderer::~Renderer (renderer.cpp:321). */
+void sdfhip_renderer_destroy(sdfhip_renderer_t* r);
+/* Replaces Renderer::update() (renderer.cpp:286, 33-60): re-reads verts and faces, re-projects,
+ * rebuilds the face structure; the 2-D nearest-vertex index is rebuilt at its next use. */
+int sdfhip_renderer_update(sdfhip_renderer_t* r);
+/* Replace Renderer::render_depth / render_mask / render_nn (sdf.hpp:310-324, renderer.cpp:93-116):
+ * out is [height * width]; depth 0 = nothing there; nn -1 = nothing there unless fill_outside
+ * (then the 2-D nearest projected vertex, nanoflann's tie rule). */
+int sdfhip_renderer_render_depth(sdfhip_renderer_t* r, float* out);
+int sdfhip_renderer_render_mask(sdfhip_renderer_t* r, uint8_t* out);
+int sdfhip_renderer_render_nn(sdfhip_renderer_t* r, int fill_outside, int32_t* out);
+/* Replace Renderer::operator() / contains / nn on continuous image points (sdf.hpp:328-340,
+ * renderer.cpp:118-140, 306-319). */
+int sdfhip_renderer_depth(sdfhip_renderer_t* r, const float* points2, int64_t n, float* out);
+int sdfhip_renderer_contains(sdfhip_renderer_t* r, const float* points2, int64_t n, uint8_t* out);
+int sdfhip_renderer_nn(sdfhip_renderer_t* r, const float* points2, int64_t n, int fill_outside,
+                       int32_t* out);
+/* The same queries on device pointers, asynchronous on `stream` (no counterpart).  kind: 0 depth
+ * (float32 out), 1 mask (uint8), 2 vertex id (int32).  d_points2 == NULL: the image pixels
+ * (n = height * width). */
+int sdfhip_renderer_query_device(sdfhip_renderer_t* r, int kind, const float* d_points2, int64_t n,
+                                 int fill_outside, void* d_out, void* stream);
+/* Accessors: Renderer::verts / faces / verts_mutable / faces_mutable / own_data
+ * (sdf.hpp:348-356, renderer.cpp:288-304). */
+int sdfhip_renderer_own_data(const sdfhip_renderer_t* r);
+int sdfhip_renderer_device(const sdfhip_renderer_t* r);
+int sdfhip_renderer_width(const sdfhip_renderer_t* r);
+int sdfhip_renderer_height(const sdfhip_renderer_t* r);
+uint32_t sdfhip_renderer_num_verts(const sdfhip_renderer_t* r);
+uint32_t sdfhip_renderer_num_faces(const sdfhip_renderer_t* r);
+const float* sdfhip_renderer_verts(const sdfhip_renderer_t* r);
+const uint32_t* sdfhip_renderer_faces(const sdfhip_renderer_t* r);
+float* sdfhip_renderer_verts_mutable(sdfhip_renderer_t* r);
+uint32_t* sdfhip_renderer_faces_mutable(sdfhip_renderer_t* r);
+
 /* Page-locked host memory for the host-pointer entry points (no counterpart: the reference's
  * Eigen / numpy arrays are pageable).  Points read from, and results written to, such memory move
  * by DMA at the full PCIe rate and without blocking the calling thread; pageable memory works

@@ -73,6 +73,15 @@ def _load():
     L.orc_dist_point2lineseg.argtypes = [_fp, _fp, _fp]
     L.orc_bary2d_inside.restype = C.c_int
     L.orc_bary2d_inside.argtypes = [_fp, _fp, _fp, _fp]
+    L.orc_rend_create.restype = C.c_void_p
+    L.orc_rend_create.argtypes = [_fp, C.c_int, _up, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                  C.c_float, C.c_float]
+    L.orc_rend_destroy.argtypes = [C.c_void_p]
+    L.orc_rend_update.argtypes = [C.c_void_p]
+    L.orc_rend_get_cam.argtypes = [C.c_void_p, _fp]
+    L.orc_rend_get_face_boxes.argtypes = [C.c_void_p, _fp, _fp, _bp]
+    L.orc_rend_query.argtypes = [C.c_void_p, C.c_int, _fp, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.orc_rend_eval_candidates.argtypes = [C.c_void_p, C.c_float, C.c_float, _ip, C.c_int, _fp, _bp, _ip]
     return L
 
 
@@ -225,6 +234,92 @@ class OracleSDF:
         return tuple(out)
 
 
+def _pts2(points):
+    p = np.ascontiguousarray(points, dtype=np.float32)
+    if p.ndim == 1:
+        p = p.reshape(1, 2)
+    assert p.ndim == 2 and p.shape[1] == 2
+    return p
+
+
+class OracleRenderer:
+    """CPU restatement of sdf::Renderer (src/renderer.cpp) with the pysdf.Renderer call surface
+    (pybind.cpp:85-161).  Holds references to the numpy arrays (no copy), like Eigen::Ref."""
+
+    def __init__(self, verts, faces, width=1080, height=1080, fx=2600.0, fy=2600.0, cx=540.0, cy=540.0):
+        self.verts = np.ascontiguousarray(verts, dtype=np.float32)
+        self.faces = np.ascontiguousarray(faces, dtype=np.uint32)
+        self.width, self.height = int(width), int(height)
+        self._h = lib().orc_rend_create(_f(self.verts), self.verts.shape[0], self.faces.ctypes.data_as(_up),
+                                        self.faces.shape[0], self.width, self.height, fx, fy, cx, cy)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_rend_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def update(self):
+        lib().orc_rend_update(self._h)
+
+    def _q(self, kind, points, fill=False, n_threads=None):
+        dt = (np.float32, np.uint8, np.int32)[kind]
+        if points is None:
+            n, p = self.width * self.height, None
+        else:
+            pp = _pts2(points)
+            n, p = pp.shape[0], _f(pp)
+        out = np.empty(n, dtype=dt)
+        lib().orc_rend_query(self._h, kind, p, n, int(fill), out.ctypes.data_as(C.c_void_p),
+                             n_threads or default_threads())
+        if kind == 1:
+            out = out.view(np.bool_)
+        return out if points is not None else out.reshape(self.height, self.width)
+
+    def __call__(self, points, n_threads=None):
+        return self._q(0, points, n_threads=n_threads)
+
+    def contains(self, points, n_threads=None):
+        return self._q(1, points, n_threads=n_threads)
+
+    def nn(self, points, fill_outside=True, n_threads=None):
+        return self._q(2, points, fill_outside, n_threads)
+
+    def render_depth(self, n_threads=None):
+        return self._q(0, None, n_threads=n_threads)
+
+    def render_mask(self, n_threads=None):
+        return self._q(1, None, n_threads=n_threads)
+
+    def render_nn(self, fill_outside=False, n_threads=None):
+        return self._q(2, None, fill_outside, n_threads)
+
+    @property
+    def verts_cam(self):
+        out = np.empty((self.verts.shape[0], 2), dtype=np.float32)
+        lib().orc_rend_get_cam(self._h, _f(out))
+        return out
+
+    def face_boxes(self):
+        nf = self.faces.shape[0]
+        mn, mx = np.empty((nf, 2), np.float32), np.empty((nf, 2), np.float32)
+        valid = np.empty(nf, np.uint8)
+        lib().orc_rend_get_face_boxes(self._h, _f(mn), _f(mx), valid.ctypes.data_as(_bp))
+        return mn, mx, valid
+
+    def eval_candidates(self, px, py, cand):
+        """the reference's handlers (renderer.cpp:63-87) over `cand` in the given order"""
+        c = np.ascontiguousarray(cand, dtype=np.int32)
+        d = np.zeros(1, np.float32)
+        m = np.zeros(1, np.uint8)
+        v = np.zeros(1, np.int32)
+        lib().orc_rend_eval_candidates(self._h, float(px), float(py), c.ctypes.data_as(_ip), c.shape[0],
+                                       _f(d), m.ctypes.data_as(_bp), v.ctypes.data_as(_ip))
+        return d[0], bool(m[0]), int(v[0])
+
+
 def quat_to_R(q4):
     q = np.ascontiguousarray(q4, dtype=np.float32)
     R = np.empty((3, 3), dtype=np.float32)
@@ -258,6 +353,15 @@ def ref_lib():
         R.ref_rtree_destroy.argtypes = [C.c_void_p]
         R.ref_rtree_ray.restype = C.c_int
         R.ref_rtree_ray.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, _ip, C.c_int]
+        R.ref_kd2_create.restype = C.c_void_p
+        R.ref_kd2_create.argtypes = [_fp, C.c_int]
+        R.ref_kd2_destroy.argtypes = [C.c_void_p]
+        R.ref_kd2_nn.argtypes = [C.c_void_p, _fp, C.c_int, _ip]
+        R.ref_rtree2_create.restype = C.c_void_p
+        R.ref_rtree2_create.argtypes = [_fp, _fp, _bp, C.c_int]
+        R.ref_rtree2_destroy.argtypes = [C.c_void_p]
+        R.ref_rtree2_point.restype = C.c_int
+        R.ref_rtree2_point.argtypes = [C.c_void_p, _fp, _ip, C.c_int]
         _R = R
     return _R
 
@@ -314,5 +418,50 @@ class RefRTree:
         q = np.ascontiguousarray(q_rot, dtype=np.float32)
         n = ref_lib().ref_rtree_ray(self._h, _f(q), ax, int(inv),
                                     self._buf.ctypes.data_as(_ip), self._buf.shape[0])
+        assert n <= self._buf.shape[0]
+        return self._buf[:n].copy()
+
+
+class RefKd2:
+    """The reference's real nanoflann index with DIM = 2 (renderer.cpp:248-250)."""
+
+    def __init__(self, pts2):
+        self.pts = np.ascontiguousarray(pts2, dtype=np.float32)
+        self._h = ref_lib().ref_kd2_create(_f(self.pts), self.pts.shape[0])
+
+    def __del__(self):
+        try:
+            ref_lib().ref_kd2_destroy(self._h)
+        except Exception:
+            pass
+
+    def nn(self, points2):
+        p = _pts2(points2)
+        out = np.empty(p.shape[0], dtype=np.int32)
+        ref_lib().ref_kd2_nn(self._h, _f(p), p.shape[0], out.ctypes.data_as(_ip))
+        return out
+
+
+class RefRTree2:
+    """The reference's real RTree<int, float, 2> over per-face image-space boxes (renderer.cpp:42-59)."""
+
+    def __init__(self, bmin, bmax, valid):
+        self.bmin = np.ascontiguousarray(bmin, dtype=np.float32)
+        self.bmax = np.ascontiguousarray(bmax, dtype=np.float32)
+        self.valid = np.ascontiguousarray(valid, dtype=np.uint8)
+        self._h = ref_lib().ref_rtree2_create(_f(self.bmin), _f(self.bmax), self.valid.ctypes.data_as(_bp),
+                                              self.bmin.shape[0])
+        self._buf = np.empty(1 << 16, dtype=np.int32)
+
+    def __del__(self):
+        try:
+            ref_lib().ref_rtree2_destroy(self._h)
+        except Exception:
+            pass
+
+    def point(self, q2):
+        """candidate face ids of the degenerate box [q, q], in the R-tree's search order"""
+        q = np.ascontiguousarray(q2, dtype=np.float32)
+        n = ref_lib().ref_rtree2_point(self._h, _f(q), self._buf.ctypes.data_as(_ip), self._buf.shape[0])
         assert n <= self._buf.shape[0]
         return self._buf[:n].copy()

@@ -46,9 +46,78 @@ struct RefRTree {
     RTree<int, float, 3> tree;
 };
 
+// 2-D variants as sdf::Renderer configures them (renderer.cpp:245-250): RTree<int, float, 2> and
+// KDTreeEigenRefAdaptor<const Points2D, 2, metric_L2_Simple> (leaf_max_size 10, sdf_util.hpp:38)
+struct PointCloud2 {
+    const float* p;
+    size_t n;
+    inline size_t kdtree_get_point_count() const { return n; }
+    inline float kdtree_get_pt(const size_t idx, int dim) const { return p[2 * idx + dim]; }
+    template <class BBOX>
+    bool kdtree_get_bbox(BBOX&) const {
+        return false;
+    }
+};
+using Metric2 = nanoflann::metric_L2_Simple::traits<float, PointCloud2>::distance_t;
+using KdIndex2 = nanoflann::KDTreeSingleIndexAdaptor<Metric2, PointCloud2, 2, int>;
+struct RefKd2 {
+    PointCloud2 cloud;
+    KdIndex2* index;
+};
+struct RefRTree2 {
+    RTree<int, float, 2> tree;
+};
+
 }  // namespace
 
 extern "C" {
+
+void* ref_kd2_create(const float* pts2, int n) {
+    RefKd2* r = new RefKd2();
+    r->cloud.p = pts2;
+    r->cloud.n = (size_t)n;
+    r->index = new KdIndex2(2, r->cloud, nanoflann::KDTreeSingleIndexAdaptorParams(10));
+    r->index->buildIndex();
+    return r;
+}
+void ref_kd2_destroy(void* h) {
+    RefKd2* r = (RefKd2*)h;
+    delete r->index;
+    delete r;
+}
+// same call as renderer.cpp:197-204 / 229-236
+void ref_kd2_nn(void* h, const float* q2, int n, int32_t* out) {
+    RefKd2* r = (RefKd2*)h;
+    for (int i = 0; i < n; ++i) {
+        size_t index = (size_t)-1;
+        float dist;
+        nanoflann::KNNResultSet<float> rs(1);
+        rs.init(&index, &dist);
+        r->index->findNeighbors(rs, q2 + 2 * (size_t)i, nanoflann::SearchParams(10));
+        out[i] = (int32_t)index;
+    }
+}
+// R-tree over the per-face 2-D boxes, inserted in face order, NaN boxes skipped (renderer.cpp:42-59)
+void* ref_rtree2_create(const float* bmin2, const float* bmax2, const uint8_t* valid, int nf) {
+    RefRTree2* r = new RefRTree2();
+    for (int i = 0; i < nf; ++i)
+        if (valid[i]) r->tree.Insert(bmin2 + 2 * (size_t)i, bmax2 + 2 * (size_t)i, i);
+    return r;
+}
+void ref_rtree2_destroy(void* h) { delete (RefRTree2*)h; }
+// candidates of the degenerate box [q, q] IN SEARCH ORDER (renderer.cpp:170-173)
+int ref_rtree2_point(void* h, const float* q2, int32_t* out, int cap) {
+    RefRTree2* r = (RefRTree2*)h;
+    float mn[2] = {q2[0], q2[1]}, mx[2] = {q2[0], q2[1]};
+    int cnt = 0;
+    r->tree.Search(mn, mx, [&](const int& id) -> bool {
+        if (cnt < cap) out[cnt] = id;
+        ++cnt;
+        return true;
+    });
+    return cnt;
+}
+
 
 void* ref_kd_create(const float* pts, int n) {
     RefKd* r = new RefKd();

@@ -786,3 +786,261 @@ int orc_bary2d_inside(const float* p, const float* a, const float* b, const floa
 }
 
 }  // extern "C"
+
+// =========================================================================================
+// sdf::Renderer (src/renderer.cpp, sdf.hpp:282-369): image-space raycaster.
+// TEST INFRASTRUCTURE ONLY, like the rest of this file.
+//
+// Parity status:
+//   * candidate faces of a 2-D point (RTree<int,float,2>::Search of a degenerate box,
+//     renderer.cpp:170-173) and the 2-D nearest vertex of fill_outside (nanoflann DIM = 2,
+//     renderer.cpp:196-204, 248-250): PINNED against the real vendored headers through
+//     oracle/ref_shim.cpp (ref_rtree2_*, ref_kd2_*); tests/test_oracle_renderer.py.
+//   * depth and mask do not depend on the visiting order (min / any).  The vertex id does when
+//     two DIFFERENT vertices with exactly equal z compete (renderer.cpp:84 keeps the first
+//     visited): orc_rend_eval_candidates applies the handlers in a GIVEN order (used with the
+//     real R-tree's order); the restatement's own rule is order independent: lowest z, then
+//     lowest face id.
+//   * bary2d arithmetic (sdf.hpp:130-142) is plain float C++, no Eigen reduction beyond
+//     tail<2>().sum() = b1 + b2; the projection (renderer.cpp:37-40) is elementwise.
+// =========================================================================================
+namespace orc {
+
+struct Bary {
+    float b0, b1, b2;
+};
+// sdf.hpp:130-142
+static inline Bary bary2d(float px, float py, float ax, float ay, float bx, float by, float cx,
+                          float cy) {
+    float v0x = bx - ax, v0y = by - ay, v1x = cx - ax, v1y = cy - ay, v2x = px - ax, v2y = py - ay;
+    float invden = 1.f / (v0x * v1y - v1x * v0y);
+    Bary r;
+    r.b1 = (v2x * v1y - v1x * v2y) * invden;
+    r.b2 = (v0x * v2y - v2x * v0y) * invden;
+    r.b0 = 1.0f - (r.b1 + r.b2);
+    return r;
+}
+
+struct RendOracle {
+    const float* verts;  // caller memory, re-read on update (Eigen::Ref, renderer.cpp:143)
+    const uint32_t* faces;
+    int nv, nf, width, height;
+    float fx, fy, cx, cy;
+    std::vector<float> cam;         // verts_cam [nv,2] (renderer.cpp:37-40)
+    std::vector<float> bmin, bmax;  // per-face 2-D AABB (renderer.cpp:46-51)
+    std::vector<uint8_t> valid;     // 0: NaN box, not inserted (renderer.cpp:52-56)
+    std::vector<float> cam3;        // verts_cam embedded as (x, y, 0) for the kd restatement
+    KdTree kd;
+    bool kd_ready = false;
+    // candidate filter (any superset + the exact per-face test gives the R-tree's hit set)
+    int g = 1;
+    float o0 = 0, o1 = 0, inv0 = 0, inv1 = 0;
+    std::vector<int> start, items;
+
+    int cell(float v, float o, float inv) const {
+        float f = std::floor((v - o) * inv);
+        if (!(f > 0.f)) return 0;
+        if (f >= (float)(g - 1)) return g - 1;
+        return (int)f;
+    }
+
+    void update() {
+        kd_ready = false;
+        cam.resize(2 * (size_t)nv);
+        for (int i = 0; i < nv; ++i) {
+            const float z = verts[3 * (size_t)i + 2];
+            cam[2 * (size_t)i] = (verts[3 * (size_t)i] * fx) / z + cx;
+            cam[2 * (size_t)i + 1] = (verts[3 * (size_t)i + 1] * fy) / z + cy;
+        }
+        bmin.assign(2 * (size_t)nf, 0.f);
+        bmax.assign(2 * (size_t)nf, 0.f);
+        valid.assign(nf, 0);
+        float lo0 = FLT_MAX, lo1 = FLT_MAX, hi0 = -FLT_MAX, hi1 = -FLT_MAX;
+        for (int f = 0; f < nf; ++f) {
+            const float* a = &cam[2 * (size_t)faces[3 * (size_t)f]];
+            const float* b = &cam[2 * (size_t)faces[3 * (size_t)f + 1]];
+            const float* c = &cam[2 * (size_t)faces[3 * (size_t)f + 2]];
+            for (int d = 0; d < 2; ++d) {
+                float mn = a[d], mx = a[d];
+                mn = stdmin(mn, b[d]), mn = stdmin(mn, c[d]);
+                mx = stdmax(mx, b[d]), mx = stdmax(mx, c[d]);
+                bmin[2 * (size_t)f + d] = mn, bmax[2 * (size_t)f + d] = mx;
+            }
+            valid[f] = !(std::isnan(bmin[2 * (size_t)f]) || std::isnan(bmin[2 * (size_t)f + 1]) ||
+                         std::isnan(bmax[2 * (size_t)f]) || std::isnan(bmax[2 * (size_t)f + 1]));
+            if (valid[f]) {
+                for (int d = 0; d < 2; ++d) {
+                    const float mn = bmin[2 * (size_t)f + d], mx = bmax[2 * (size_t)f + d];
+                    float& lo = d ? lo1 : lo0;
+                    float& hi = d ? hi1 : hi0;
+                    if (std::fabs(mn) <= FLT_MAX && mn < lo) lo = mn;
+                    if (std::fabs(mx) <= FLT_MAX && mx > hi) hi = mx;
+                }
+            }
+        }
+        if (!(lo0 <= hi0)) lo0 = hi0 = 0;
+        if (!(lo1 <= hi1)) lo1 = hi1 = 0;
+        g = std::max(1, std::min((int)std::sqrt((double)nf / 2.0), 2048));
+        o0 = lo0, o1 = lo1;
+        inv0 = (hi0 > lo0) ? (float)g / (hi0 - lo0) : 0.f;
+        inv1 = (hi1 > lo1) ? (float)g / (hi1 - lo1) : 0.f;
+        std::vector<int> cnt((size_t)g * g + 1, 0);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int f = 0; f < nf; ++f) {
+                if (!valid[f]) continue;
+                const int a0 = cell(bmin[2 * (size_t)f], o0, inv0), a1 = cell(bmax[2 * (size_t)f], o0, inv0);
+                const int b0 = cell(bmin[2 * (size_t)f + 1], o1, inv1), b1 = cell(bmax[2 * (size_t)f + 1], o1, inv1);
+                for (int a = a0; a <= a1; ++a)
+                    for (int b = b0; b <= b1; ++b) {
+                        if (pass == 0)
+                            cnt[(size_t)a * g + b + 1]++;
+                        else
+                            items[cnt[(size_t)a * g + b]++] = f;
+                    }
+            }
+            if (pass == 0) {
+                for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+                start = cnt;
+                items.assign((size_t)start.back(), 0);
+            }
+        }
+    }
+
+    // one face against one point: RTree Overlap of the degenerate box (RTree.h:1427-1438, closed
+    // intervals) && bary2d >= 0 (renderer.cpp:160-169).  Returns false if the face is not hit.
+    bool hit(int f, float px, float py, Bary& b) const {
+        if (!valid[f]) return false;
+        if (px > bmax[2 * (size_t)f] || bmin[2 * (size_t)f] > px || py > bmax[2 * (size_t)f + 1] ||
+            bmin[2 * (size_t)f + 1] > py)
+            return false;
+        const uint32_t* fc = faces + 3 * (size_t)f;
+        b = bary2d(px, py, cam[2 * (size_t)fc[0]], cam[2 * (size_t)fc[0] + 1], cam[2 * (size_t)fc[1]],
+                   cam[2 * (size_t)fc[1] + 1], cam[2 * (size_t)fc[2]], cam[2 * (size_t)fc[2] + 1]);
+        return b.b0 >= 0.f && b.b1 >= 0.f && b.b2 >= 0.f;
+    }
+    // renderer.cpp:63-70
+    float face_depth(int f, const Bary& b) const {
+        const uint32_t* fc = faces + 3 * (size_t)f;
+        return verts[3 * (size_t)fc[0] + 2] * b.b0 + verts[3 * (size_t)fc[1] + 2] * b.b1 +
+               verts[3 * (size_t)fc[2] + 2] * b.b2;
+    }
+    // renderer.cpp:78-83
+    int face_close_vert(int f, const Bary& b) const {
+        const float bb[3] = {b.b0, b.b1, b.b2};
+        int cv = 0;
+        for (int i = 1; i < 3; ++i)
+            if (bb[i] > bb[cv]) cv = i;
+        return (int)faces[3 * (size_t)f + cv];
+    }
+
+    struct Pix {
+        float depth = FLT_MAX;
+        bool mask = false;
+        int vertex = -1;
+        int vface = -1;  // face that supplied `vertex` (order-independent rule)
+    };
+    // handlers applied to one hit, reference order semantics (renderer.cpp:63-87)
+    void apply_ordered(Pix& p, int f, const Bary& b) const {
+        p.depth = stdmin(p.depth, face_depth(f, b));
+        p.mask = true;
+        const int cand = face_close_vert(f, b);
+        if (p.vertex == -1 || verts[3 * (size_t)cand + 2] < verts[3 * (size_t)p.vertex + 2]) p.vertex = cand;
+    }
+    // same, with the order-independent vertex rule: lowest z, then lowest face id
+    void apply_canonical(Pix& p, int f, const Bary& b) const {
+        p.depth = stdmin(p.depth, face_depth(f, b));
+        p.mask = true;
+        const int cand = face_close_vert(f, b);
+        const float zc = verts[3 * (size_t)cand + 2];
+        if (p.vertex == -1) {
+            p.vertex = cand, p.vface = f;
+        } else {
+            const float zv = verts[3 * (size_t)p.vertex + 2];
+            if (zc < zv || (zc == zv && f < p.vface)) p.vertex = cand, p.vface = f;
+        }
+    }
+    Pix query(float px, float py) const {
+        Pix p;
+        const int c = cell(px, o0, inv0) * g + cell(py, o1, inv1);
+        Bary b;
+        for (int k = start[c]; k < start[c + 1]; ++k)
+            if (hit(items[k], px, py, b)) apply_canonical(p, items[k], b);
+        return p;
+    }
+    int nn2d(float px, float py) {
+        const float q[3] = {px, py, 0.f};
+        return (int)kd.find(q).index;
+    }
+    void ensure_kd() {  // renderer.cpp:110-113: lazy rebuild
+        if (kd_ready) return;
+        cam3.resize(3 * (size_t)nv);
+        for (int i = 0; i < nv; ++i)
+            cam3[3 * (size_t)i] = cam[2 * (size_t)i], cam3[3 * (size_t)i + 1] = cam[2 * (size_t)i + 1],
+                            cam3[3 * (size_t)i + 2] = 0.f;
+        kd.build(cam3.data(), nv);
+        kd_ready = true;
+    }
+};
+
+}  // namespace orc
+
+extern "C" {
+
+void* orc_rend_create(const float* verts, int nv, const uint32_t* faces, int nf, int width, int height,
+                      float fx, float fy, float cx, float cy) {
+    orc::RendOracle* r = new orc::RendOracle();
+    r->verts = verts, r->faces = faces, r->nv = nv, r->nf = nf;
+    r->width = width, r->height = height, r->fx = fx, r->fy = fy, r->cx = cx, r->cy = cy;
+    r->update();
+    return r;
+}
+void orc_rend_destroy(void* h) { delete (orc::RendOracle*)h; }
+void orc_rend_update(void* h) { ((orc::RendOracle*)h)->update(); }
+void orc_rend_get_cam(void* h, float* out) {
+    orc::RendOracle* r = (orc::RendOracle*)h;
+    std::memcpy(out, r->cam.data(), r->cam.size() * sizeof(float));
+}
+void orc_rend_get_face_boxes(void* h, float* mn, float* mx, uint8_t* valid) {
+    orc::RendOracle* r = (orc::RendOracle*)h;
+    std::memcpy(mn, r->bmin.data(), r->bmin.size() * sizeof(float));
+    std::memcpy(mx, r->bmax.data(), r->bmax.size() * sizeof(float));
+    std::memcpy(valid, r->valid.data(), r->valid.size());
+}
+// pts == nullptr: the image, pixel i = (float)(i % width), (float)(i / width) (renderer.cpp:187-189)
+// kind 0 depth (float out, FLT_MAX -> 0), 1 mask (uint8), 2 vertex (int32; fill_outside: 2-D nn)
+void orc_rend_query(void* h, int kind, const float* pts, int n, int fill_outside, void* out, int n_threads) {
+    orc::RendOracle* r = (orc::RendOracle*)h;
+    if (kind == 2 && fill_outside) r->ensure_kd();
+    orc::parallel_for(
+        [&](int i) {
+            const float px = pts ? pts[2 * (size_t)i] : (float)(i % r->width);
+            const float py = pts ? pts[2 * (size_t)i + 1] : (float)(i / r->width);
+            const orc::RendOracle::Pix p = r->query(px, py);
+            if (kind == 0) {
+                ((float*)out)[i] = p.depth == FLT_MAX ? 0.0f : p.depth;  // renderer.cpp:193-194
+            } else if (kind == 1) {
+                ((uint8_t*)out)[i] = p.mask;
+            } else {
+                int v = p.vertex;
+                if (fill_outside && v < 0) v = r->nn2d(px, py);  // renderer.cpp:196-204
+                ((int32_t*)out)[i] = v;
+            }
+        },
+        n, n_threads);
+}
+// the handlers applied to a GIVEN candidate list in its order (the real R-tree's search order):
+// out3 = {depth bits, mask, vertex}.  The mask handler's early exit (renderer.cpp:72-76) does not
+// change any of the three.
+void orc_rend_eval_candidates(void* h, float px, float py, const int32_t* cand, int ncand, float* depth,
+                              uint8_t* mask, int32_t* vertex) {
+    orc::RendOracle* r = (orc::RendOracle*)h;
+    orc::RendOracle::Pix p;
+    orc::Bary b;
+    for (int k = 0; k < ncand; ++k)
+        if (r->hit(cand[k], px, py, b)) r->apply_ordered(p, cand[k], b);
+    *depth = p.depth == FLT_MAX ? 0.0f : p.depth;
+    *mask = p.mask;
+    *vertex = p.vertex;
+}
+
+}  // extern "C"

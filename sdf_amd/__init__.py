@@ -2,7 +2,7 @@
 
 `from sdf_amd import SDF` is the drop-in for `from pysdf import SDF`.
 """
-from .pysdf import SDF, SdfHipError, load_library, num_threads, pinned_empty  # noqa: F401
+from .pysdf import SDF, Renderer, SdfHipError, load_library, num_threads, pinned_empty  # noqa: F401
 from . import meshes  # noqa: F401
 
-__all__ = ["SDF", "SdfHipError", "load_library", "num_threads", "pinned_empty", "meshes"]
+__all__ = ["SDF", "Renderer", "SdfHipError", "load_library", "num_threads", "pinned_empty", "meshes"]

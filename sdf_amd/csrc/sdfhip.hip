@@ -1293,6 +1293,12 @@ __device__ __forceinline__ uint32_t f2ord(float f) {
 __device__ __forceinline__ float ord2f(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
+static inline float ord2f_host(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float f;
+    std::memcpy(&f, &u, sizeof(f));
+    return f;
+}
 __global__ void k_bounds_init(uint32_t* b) {
     if (threadIdx.x < 3) b[threadIdx.x] = 0xFFFFFFFFu;
     else if (threadIdx.x < 6) b[threadIdx.x] = 0u;
@@ -1559,10 +1565,12 @@ template <bool FILL>
 __global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridParams G,
                              uint32_t* __restrict__ cells /* counts | cursors */,
                              uint32_t* __restrict__ items, uint32_t* __restrict__ big,
-                             uint32_t* __restrict__ nbig) {
+                             uint32_t* __restrict__ nbig, int skip_nan) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nf) return;
     const float* b = fbox + 6 * (size_t)f;
+    // Renderer: a face whose image-space box has a NaN is never inserted (renderer.cpp:52-56)
+    if (skip_nan && (b[0] != b[0] || b[1] != b[1] || b[3] != b[3] || b[4] != b[4])) return;
     const int x0 = grid_cell(b[0], G.o0, G.inv0, G.g), x1 = grid_cell(b[3], G.o0, G.inv0, G.g);
     const int y0 = grid_cell(b[1], G.o1, G.inv1, G.g), y1 = grid_cell(b[4], G.o1, G.inv1, G.g);
     if (x1 < x0 || y1 < y0) return;  // NaN box: the face can never pass Overlap
@@ -1599,6 +1607,30 @@ __global__ void k_lbvh_fit(int n, LbvhTopo T, uint32_t depth, float4* __restrict
 // =========================================================================================
 // handle
 // =========================================================================================
+// A column grid: cell -> ids of the faces whose 2-D box touches it (CSR), plus the "big" list of
+// faces spanning more than GRID_BIG cells.  Used over (x', y') of the ray-cast frame by SDF and
+// over the image plane by Renderer.
+struct GridBuf {
+    uint32_t* start = nullptr;   // [g*g + 1]
+    uint32_t* cursor = nullptr;
+    uint32_t* items = nullptr;
+    uint32_t* big = nullptr;
+    uint32_t* nbig_dev = nullptr;
+    uint32_t* s1 = nullptr;
+    uint32_t* s2 = nullptr;
+    size_t cells_cap = 0, items_cap = 0, big_cap = 0;
+    uint32_t nbig = 0, entries = 0;
+    bool coarsened = false;  // faces are large against the cells at the natural resolution
+    GridParams gr = {1, 0.f, 0.f, 0.f, 0.f};
+    void release() {
+        void* ps[] = {start, cursor, items, big, nbig_dev, s1, s2};
+        for (void* p : ps)
+            if (p) (void)hipFree(p);
+        start = cursor = items = big = nbig_dev = s1 = s2 = nullptr;
+        cells_cap = items_cap = big_cap = 0;
+    }
+};
+
 struct sdfhip_ctx {
     int device = 0;
     bool robust = true, own = false;
@@ -1647,16 +1679,7 @@ struct sdfhip_ctx {
     float total_area = 0.f;
     float* d_fbox = nullptr;
     // column grid (rebuilt by every update: face boxes move)
-    uint32_t* d_gr_start = nullptr;
-    uint32_t* d_gr_cursor = nullptr;
-    uint32_t* d_gr_items = nullptr;
-    uint32_t* d_gr_big = nullptr;
-    uint32_t* d_gr_nbig = nullptr;
-    uint32_t* d_gr_s1 = nullptr;
-    uint32_t* d_gr_s2 = nullptr;
-    size_t gr_cells_cap = 0, gr_items_cap = 0;
-    uint32_t gr_nbig = 0, gr_entries = 0;
-    bool gr_coarsened = false;
+    GridBuf grid;
     // fast_nn mode (GPU-built vertex tree)
     int64_t opt_fast_nn = 0;   // applies at the next update
     bool fast_active = false;  // what the structures on the device currently are
@@ -1665,7 +1688,6 @@ struct sdfhip_ctx {
     uint32_t* d_vidx = nullptr;
     size_t vkeys_cap = 0;
     int64_t opt_ray_mode = 0;  // 0 automatic, 1 column grid, 2 cooperative LBVH (packet kernel)
-    GridParams gr = {1, 0.f, 0.f, 0.f, 0.f};
     float* d_normals = nullptr;
     float* d_areas = nullptr;
     float4* d_rnodes = nullptr;
@@ -1747,6 +1769,80 @@ void draw_rotation(sdfhip_ctx* h) {
     R[6] = txz - twy, R[7] = tyz + twx, R[8] = 1 - (txx + tyy);
 }
 
+// (Re)builds `B` over n face boxes (6 floats each: min xyz, max xyz; x and y are used) whose
+// x / y range is [lo, hi]: count -> scan -> fill, three small launches (+ one retry per halving
+// when the faces are large against the cells).
+int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], const float hi[2],
+               int skip_nan, hipStream_t s) {
+    if (n == 0) {  // no faces: one empty cell (the query kernels always look their cell up)
+        if (B.cells_cap < 2) {
+            if (int rc = dalloc(&B.start, 2)) return rc;
+            B.cells_cap = 2;
+        }
+        HIPC(hipMemsetAsync(B.start, 0, 2 * sizeof(uint32_t), s));
+        B.gr = {1, 0.f, 0.f, 0.f, 0.f};
+        B.nbig = 0, B.entries = 0, B.coarsened = false;
+        return 0;
+    }
+    int g = (int)std::sqrt((double)n);
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    const int g_first = g;
+    bool long_lists = false;  // > 10 cells per face at the natural resolution
+    if (!B.nbig_dev)
+        if (int rc = dalloc(&B.nbig_dev, 1)) return rc;
+    if ((size_t)n > B.big_cap) {
+        if (int rc = dalloc(&B.big, n)) return rc;
+        B.big_cap = n;
+    }
+    for (;;) {
+        GridParams G;
+        G.g = g;
+        G.o0 = lo[0], G.o1 = lo[1];
+        const float e0 = hi[0] - lo[0], e1 = hi[1] - lo[1];
+        G.inv0 = (e0 > 0.f && e0 < FLT_MAX) ? (float)g / e0 : 0.f;
+        G.inv1 = (e1 > 0.f && e1 < FLT_MAX) ? (float)g / e1 : 0.f;
+        const size_t cells = (size_t)g * g + 1;
+        if (cells > B.cells_cap || !B.cursor) {
+            if (int rc = dalloc(&B.start, cells)) return rc;
+            if (int rc = dalloc(&B.cursor, cells)) return rc;
+            if (int rc = dalloc(&B.s1, cells / 2048 + 4)) return rc;
+            if (int rc = dalloc(&B.s2, cells / 2048 / 2048 + 4)) return rc;
+            B.cells_cap = cells;
+        }
+        HIPC(hipMemsetAsync(B.start, 0, sizeof(uint32_t) * cells, s));
+        HIPC(hipMemsetAsync(B.nbig_dev, 0, sizeof(uint32_t), s));
+        k_grid_faces<false><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.start, nullptr, B.big,
+                                                            B.nbig_dev, skip_nan);
+        exclusive_scan_u32(B.start, (uint32_t)cells, B.s1, B.s2, s);
+        uint32_t total = 0, nbig = 0;
+        HIPC(hipMemcpyAsync(&total, B.start + (cells - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPC(hipMemcpyAsync(&nbig, B.nbig_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPC(hipStreamSynchronize(s));
+        if (g == g_first) long_lists = (size_t)total + 256 * (size_t)nbig > 10 * (size_t)n;
+        // many faces much larger than a cell: a coarser grid keeps the lists (and memory) short
+        if (((size_t)total > 16 * (size_t)n + 4096 || (size_t)nbig > (size_t)n / 64 + 16) && g > 1) {
+            g = g / 2;
+            continue;
+        }
+        if ((size_t)total + 1 > B.items_cap) {
+            const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
+            if (int rc = dalloc(&B.items, cap)) return rc;
+            B.items_cap = cap;
+        }
+        HIPC(hipMemcpyAsync(B.cursor, B.start, sizeof(uint32_t) * cells, hipMemcpyDeviceToDevice, s));
+        k_grid_faces<true><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.cursor, B.items, B.big,
+                                                           B.nbig_dev, skip_nan);
+        HIPC(hipGetLastError());
+        B.gr = G;
+        B.coarsened = long_lists;
+        B.nbig = nbig;
+        B.entries = total;
+        if (std::getenv("SDFHIP_DEBUG"))
+            std::fprintf(stderr, "[sdfhip] column grid g=%d (first %d) entries=%u big=%u faces=%u\n", g, g_first, total, nbig, n);
+        return 0;
+    }
+}
+
 int build_topology(sdfhip_ctx* h) {
     const uint32_t n = h->nf;
     hipStream_t s = h->stream;
@@ -1803,9 +1899,6 @@ int refit(sdfhip_ctx* h) {
 
 // column grid over the rotated face boxes (d_fbox must be current on the stream)
 int build_grid(sdfhip_ctx* h) {
-    const uint32_t n = h->nf;
-    hipStream_t s = h->stream;
-    if (n == 0) return 0;
     // range of x', y': rotated corners of the world AABB (covers every face box up to rounding;
     // anything outside lands in the clamped border cells, on both the face and the query side)
     float lo[2] = {FLT_MAX, FLT_MAX}, hi[2] = {-FLT_MAX, -FLT_MAX};
@@ -1817,61 +1910,7 @@ int build_grid(sdfhip_ctx* h) {
             hi[d] = r > hi[d] ? r : hi[d];
         }
     }
-    int g = (int)std::sqrt((double)n);
-    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
-    const int g_first = g;
-    bool long_lists = false;  // > 10 cells per face at the natural resolution
-    if (!h->d_gr_nbig) {
-        if (int rc = dalloc(&h->d_gr_nbig, 1)) return rc;
-        if (int rc = dalloc(&h->d_gr_big, n)) return rc;
-    }
-    for (;;) {
-        GridParams G;
-        G.g = g;
-        G.o0 = lo[0], G.o1 = lo[1];
-        const float e0 = hi[0] - lo[0], e1 = hi[1] - lo[1];
-        G.inv0 = (e0 > 0.f && e0 < FLT_MAX) ? (float)g / e0 : 0.f;
-        G.inv1 = (e1 > 0.f && e1 < FLT_MAX) ? (float)g / e1 : 0.f;
-        const size_t cells = (size_t)g * g + 1;
-        if (cells > h->gr_cells_cap) {
-            if (int rc = dalloc(&h->d_gr_start, cells)) return rc;
-            if (int rc = dalloc(&h->d_gr_cursor, cells)) return rc;
-            if (int rc = dalloc(&h->d_gr_s1, cells / 2048 + 4)) return rc;
-            if (int rc = dalloc(&h->d_gr_s2, cells / 2048 / 2048 + 4)) return rc;
-            h->gr_cells_cap = cells;
-        }
-        HIPC(hipMemsetAsync(h->d_gr_start, 0, sizeof(uint32_t) * cells, s));
-        HIPC(hipMemsetAsync(h->d_gr_nbig, 0, sizeof(uint32_t), s));
-        k_grid_faces<false><<<(n + 255) / 256, 256, 0, s>>>(h->d_fbox, n, G, h->d_gr_start, nullptr,
-                                                            h->d_gr_big, h->d_gr_nbig);
-        exclusive_scan_u32(h->d_gr_start, (uint32_t)cells, h->d_gr_s1, h->d_gr_s2, s);
-        uint32_t total = 0, nbig = 0;
-        HIPC(hipMemcpyAsync(&total, h->d_gr_start + (cells - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPC(hipMemcpyAsync(&nbig, h->d_gr_nbig, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPC(hipStreamSynchronize(s));
-        if (g == g_first) long_lists = (size_t)total + 256 * (size_t)nbig > 10 * (size_t)n;
-        // many faces much larger than a cell: a coarser grid keeps the lists (and memory) short
-        if (((size_t)total > 16 * (size_t)n + 4096 || (size_t)nbig > (size_t)n / 64 + 16) && g > 1) {
-            g = g / 2;
-            continue;
-        }
-        if ((size_t)total + 1 > h->gr_items_cap) {
-            const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
-            if (int rc = dalloc(&h->d_gr_items, cap)) return rc;
-            h->gr_items_cap = cap;
-        }
-        HIPC(hipMemcpyAsync(h->d_gr_cursor, h->d_gr_start, sizeof(uint32_t) * cells, hipMemcpyDeviceToDevice, s));
-        k_grid_faces<true><<<(n + 255) / 256, 256, 0, s>>>(h->d_fbox, n, G, h->d_gr_cursor, h->d_gr_items,
-                                                           h->d_gr_big, h->d_gr_nbig);
-        HIPC(hipGetLastError());
-        h->gr = G;
-        h->gr_coarsened = long_lists;
-        h->gr_nbig = nbig;
-        h->gr_entries = total;
-        if (std::getenv("SDFHIP_DEBUG"))
-            std::fprintf(stderr, "[sdfhip] column grid g=%d (first %d) entries=%u big=%u faces=%u\n", g, g_first, total, nbig, n);
-        return 0;
-    }
+    return grid_build(h->grid, h->d_fbox, h->nf, lo, hi, 0, h->stream);
 }
 
 // rotation-dependent + vertex-dependent precompute; verts must already be in d_verts
@@ -2094,16 +2133,16 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.n_rnodes = h->robust ? h->n_rnodes : 0;
     M.rface = h->d_rface;
     M.fbox = h->d_fbox;
-    M.gr_start = h->d_gr_start;
-    M.gr_items = h->d_gr_items;
-    M.gr_big = h->d_gr_big;
-    M.gr_nbig = h->robust ? h->gr_nbig : 0;
-    M.gr_g = h->gr.g;
+    M.gr_start = h->grid.start;
+    M.gr_items = h->grid.items;
+    M.gr_big = h->grid.big;
+    M.gr_nbig = h->robust ? h->grid.nbig : 0;
+    M.gr_g = h->grid.gr.g;
     // automatic: faces that touch > 10 cells each at the natural resolution are large against
     // the cells and the per-lane lists are long; the wave-cooperative LBVH walk shares them
     // among 64 lanes
-    M.ray_lbvh = h->opt_ray_mode == 2 || (h->opt_ray_mode == 0 && h->gr_coarsened) ? 1 : 0;
-    M.gr_o0 = h->gr.o0, M.gr_o1 = h->gr.o1, M.gr_inv0 = h->gr.inv0, M.gr_inv1 = h->gr.inv1;
+    M.ray_lbvh = h->opt_ray_mode == 2 || (h->opt_ray_mode == 0 && h->grid.coarsened) ? 1 : 0;
+    M.gr_o0 = h->grid.gr.o0, M.gr_o1 = h->grid.gr.o1, M.gr_inv0 = h->grid.gr.inv0, M.gr_inv1 = h->grid.gr.inv1;
     for (int d = 0; d < 9; ++d) M.R[d] = h->R[d];
     return M;
 }
@@ -2589,8 +2628,7 @@ void sdfhip_destroy(sdfhip_t* h) {
     DevGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_qn, h->d_kd_vind, h->d_adj_off,
-                    h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_gr_start, h->d_gr_cursor, h->d_gr_items,
-                    h->d_gr_big, h->d_gr_nbig, h->d_gr_s1, h->d_gr_s2, h->d_normals, h->d_areas,
+                    h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
                     h->topo.depthI, h->d_qkeys, h->d_qperm, h->d_qbounds, h->d_gstack, h->d_kd_pts4,
@@ -2599,6 +2637,7 @@ void sdfhip_destroy(sdfhip_t* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->sorter.release();
+    h->grid.release();
     for (int k = 0; k < 2; ++k) {
         if (h->d_stage_in[k]) (void)hipFree(h->d_stage_in[k]);
         if (h->d_stage_out[k]) (void)hipFree(h->d_stage_out[k]);
@@ -2850,3 +2889,5 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
 }
 
 }  // extern "C"
+
+#include "renderer.h"

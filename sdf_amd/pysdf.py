@@ -56,6 +56,13 @@ ABI_SYMBOLS = [
     "sdfhip_set_option", "sdfhip_last_error", "sdfhip_version",
     "sdfhip_sample_surface", "sdfhip_sample_surface_device",
     "sdfhip_host_alloc", "sdfhip_host_free",
+    "sdfhip_renderer_create", "sdfhip_renderer_destroy", "sdfhip_renderer_update",
+    "sdfhip_renderer_render_depth", "sdfhip_renderer_render_mask", "sdfhip_renderer_render_nn",
+    "sdfhip_renderer_depth", "sdfhip_renderer_contains", "sdfhip_renderer_nn",
+    "sdfhip_renderer_query_device", "sdfhip_renderer_own_data", "sdfhip_renderer_device",
+    "sdfhip_renderer_width", "sdfhip_renderer_height", "sdfhip_renderer_num_verts",
+    "sdfhip_renderer_num_faces", "sdfhip_renderer_verts", "sdfhip_renderer_faces",
+    "sdfhip_renderer_verts_mutable", "sdfhip_renderer_faces_mutable",
 ]
 
 
@@ -118,6 +125,33 @@ def load_library():
     L.sdfhip_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.sdfhip_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.sdfhip_host_free.argtypes = [C.c_void_p]
+    L.sdfhip_renderer_create.argtypes = [_fp, C.c_uint32, _up, C.c_uint32, C.c_int, C.c_int, C.c_float,
+                                         C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                         C.POINTER(vp)]
+    L.sdfhip_renderer_destroy.restype = None
+    L.sdfhip_renderer_destroy.argtypes = [vp]
+    L.sdfhip_renderer_update.argtypes = [vp]
+    L.sdfhip_renderer_render_depth.argtypes = [vp, _fp]
+    L.sdfhip_renderer_render_mask.argtypes = [vp, _bp]
+    L.sdfhip_renderer_render_nn.argtypes = [vp, C.c_int, _ip]
+    L.sdfhip_renderer_depth.argtypes = [vp, _fp, C.c_int64, _fp]
+    L.sdfhip_renderer_contains.argtypes = [vp, _fp, C.c_int64, _bp]
+    L.sdfhip_renderer_nn.argtypes = [vp, _fp, C.c_int64, C.c_int, _ip]
+    L.sdfhip_renderer_query_device.argtypes = [vp, C.c_int, vp, C.c_int64, C.c_int, vp, vp]
+    for name in ("own_data", "device", "width", "height"):
+        getattr(L, "sdfhip_renderer_" + name).argtypes = [vp]
+    L.sdfhip_renderer_num_verts.restype = C.c_uint32
+    L.sdfhip_renderer_num_verts.argtypes = [vp]
+    L.sdfhip_renderer_num_faces.restype = C.c_uint32
+    L.sdfhip_renderer_num_faces.argtypes = [vp]
+    L.sdfhip_renderer_verts.restype = _fp
+    L.sdfhip_renderer_verts.argtypes = [vp]
+    L.sdfhip_renderer_faces.restype = _up
+    L.sdfhip_renderer_faces.argtypes = [vp]
+    L.sdfhip_renderer_verts_mutable.restype = _fp
+    L.sdfhip_renderer_verts_mutable.argtypes = [vp]
+    L.sdfhip_renderer_faces_mutable.restype = _up
+    L.sdfhip_renderer_faces_mutable.argtypes = [vp]
     L.sdfhip_last_error.restype = C.c_char_p
     L.sdfhip_version.restype = C.c_char_p
     _lib = L
@@ -438,3 +472,195 @@ class SDF:
     def __repr__(self):
         return (f"<sdf.SDF(verts.shape=({self._nv}, 3), faces.shape=({self._nf}, 3), "
                 f"robust={'True' if self.robust else 'False'})>")
+
+
+def _as_points2(points):
+    p = np.asarray(points)
+    if p.ndim == 1 and p.shape[0] == 2:
+        p = p.reshape(1, 2)
+    if p.ndim != 2 or p.shape[1] != 2:
+        raise TypeError("points must have shape (N, 2)")
+    return np.ascontiguousarray(p, dtype=np.float32)
+
+
+class Renderer:
+    """Image-space raycast renderer (depth maps, masks, vertex ids) on one MI355X.  Same call
+    surface as `pysdf.Renderer` (pybind.cpp:85-161; sdf.hpp:282-369): camera at the origin facing
+    +z, right = +x, up = -y; nothing may lie at z <= 0."""
+
+    _KIND = {"depth": (0, np.float32), "mask": (1, np.bool_), "nn": (2, np.int32)}
+
+    def __init__(self, verts, faces, width=1080, height=1080, fx=2600.0, fy=2600.0, cx=540.0,
+                 cy=540.0, copy=True, device=None):
+        L = load_library()
+        v = np.asarray(verts)
+        f = np.asarray(faces)
+        if v.ndim != 2 or v.shape[1] != 3 or f.ndim != 2 or f.shape[1] != 3:
+            raise TypeError("verts must be (V, 3) and faces (F, 3)")
+        if f.size and (f.min() < 0):
+            raise TypeError("faces must be non-negative")
+        v32 = np.ascontiguousarray(v, dtype=np.float32)
+        f32 = np.ascontiguousarray(f, dtype=np.uint32)
+        if not copy:
+            if v32 is not v and not np.shares_memory(v32, v):
+                raise TypeError("copy=False needs C-contiguous float32 verts")
+            if f32 is not f and not np.shares_memory(f32, f):
+                raise TypeError("copy=False needs C-contiguous uint32 faces")
+        self._keep = None if copy else (v32, f32)
+        h = C.c_void_p()
+        dev = -1 if device is None else int(device)
+        _check(L.sdfhip_renderer_create(v32.ctypes.data_as(_fp), v32.shape[0], f32.ctypes.data_as(_up),
+                                        f32.shape[0], int(width), int(height), float(fx), float(fy),
+                                        float(cx), float(cy), int(bool(copy)), dev, C.byref(h)))
+        self._h = h
+        self._L = L
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.sdfhip_renderer_destroy(h)
+            self._h = None
+
+    def _query(self, kind, points, fill_outside=False):
+        L = self._L
+        k, dt = self._KIND[kind]
+        if points is not None and _is_torch(points) and points.is_cuda:
+            import torch
+            t = points
+            if t.dim() == 1 and t.shape[0] == 2:
+                t = t.reshape(1, 2)
+            if t.dim() != 2 or t.shape[1] != 2:
+                raise TypeError("points must have shape (N, 2)")
+            if t.device.index != self.device:
+                raise SdfHipError("points tensor is on another GPU than the Renderer handle")
+            t = t.contiguous().float()
+            n = t.shape[0]
+            out = torch.empty(n, dtype={0: torch.float32, 1: torch.uint8, 2: torch.int32}[k], device=t.device)
+            s = torch.cuda.current_stream(t.device).cuda_stream
+            _check(L.sdfhip_renderer_query_device(self._h, k, t.data_ptr(), n, int(bool(fill_outside)),
+                                                  out.data_ptr(), s))
+            return out.bool() if k == 1 else out
+        if points is not None and _is_torch(points):
+            points = points.detach().cpu().numpy()
+        if points is None:
+            hh, ww = self.height, self.width
+            out = np.empty(hh * ww, dtype=dt)
+            if k == 0:
+                _check(L.sdfhip_renderer_render_depth(self._h, out.ctypes.data_as(_fp)))
+            elif k == 1:
+                _check(L.sdfhip_renderer_render_mask(self._h, out.ctypes.data_as(_bp)))
+            else:
+                _check(L.sdfhip_renderer_render_nn(self._h, int(bool(fill_outside)), out.ctypes.data_as(_ip)))
+            return out.reshape(hh, ww)
+        p = _as_points2(points)
+        n = p.shape[0]
+        out = np.empty(n, dtype=dt)
+        if k == 0:
+            _check(L.sdfhip_renderer_depth(self._h, p.ctypes.data_as(_fp), n, out.ctypes.data_as(_fp)))
+        elif k == 1:
+            _check(L.sdfhip_renderer_contains(self._h, p.ctypes.data_as(_fp), n, out.ctypes.data_as(_bp)))
+        else:
+            _check(L.sdfhip_renderer_nn(self._h, p.ctypes.data_as(_fp), n, int(bool(fill_outside)),
+                                        out.ctypes.data_as(_ip)))
+        return out
+
+    def __call__(self, points, n_threads=num_threads):
+        """Compute depth on 2D image-space points (0 if nothing there)"""
+        return self._query("depth", points)
+
+    def calc(self, points, n_threads=num_threads):
+        """Compute depth on 2D image-space points (0 if nothing there), alias of __call__"""
+        return self._query("depth", points)
+
+    def contains(self, points, n_threads=num_threads):
+        """True where the ray cast from (x, y, 0) in +z direction in image space hits the mesh."""
+        return self._query("mask", points)
+
+    def nn(self, points, fill_outside=True, n_threads=num_threads):
+        """Index of the closest vertex hit by a ray cast from (x, y, 0); in empty space the 2D
+        nearest neighbour if fill_outside else -1."""
+        return self._query("nn", points, fill_outside)
+
+    def render_depth(self, n_threads=num_threads):
+        """(height, width) float32 depth image, 0 = no object."""
+        return self._query("depth", None)
+
+    def render_mask(self, n_threads=num_threads):
+        """(height, width) bool silhouette."""
+        return self._query("mask", None)
+
+    def render_nn(self, fill_outside=False, n_threads=num_threads):
+        """(height, width) int32 vertex ids."""
+        return self._query("nn", None, fill_outside)
+
+    def update(self):
+        """Update the Renderer to reflect any changes in verts"""
+        _check(self._L.sdfhip_renderer_update(self._h))
+
+    @property
+    def device(self):
+        return int(self._L.sdfhip_renderer_device(self._h))
+
+    @property
+    def width(self):
+        return int(self._L.sdfhip_renderer_width(self._h))
+
+    @property
+    def height(self):
+        return int(self._L.sdfhip_renderer_height(self._h))
+
+    @property
+    def _nv(self):
+        return int(self._L.sdfhip_renderer_num_verts(self._h))
+
+    @property
+    def _nf(self):
+        return int(self._L.sdfhip_renderer_num_faces(self._h))
+
+    _view = SDF._view
+
+    @property
+    def faces(self):
+        return self._view(self._L.sdfhip_renderer_faces(self._h), (self._nf, 3), np.uint32, False)
+
+    @property
+    def verts(self):
+        return self._view(self._L.sdfhip_renderer_verts(self._h), (self._nv, 3), np.float32, False)
+
+    vertices = verts
+
+    @property
+    def own_data(self):
+        return bool(self._L.sdfhip_renderer_own_data(self._h))
+
+    def _mutable(self, which):
+        import sys
+        if not self.own_data:  # renderer.cpp:289-304: prints and returns the (empty) owned matrix
+            print(f"ERROR: '{which}' is non mutable, construct with copy=True", file=sys.stderr)
+            return np.zeros((0, 3), dtype=np.float32 if which == "verts" else np.uint32)
+        if which == "verts":
+            return self._view(self._L.sdfhip_renderer_verts_mutable(self._h), (self._nv, 3), np.float32, True)
+        return self._view(self._L.sdfhip_renderer_faces_mutable(self._h), (self._nf, 3), np.uint32, True)
+
+    @property
+    def verts_mutable(self):
+        return self._mutable("verts")
+
+    @verts_mutable.setter
+    def verts_mutable(self, val):
+        dst = self._mutable("verts")
+        dst[...] = np.asarray(val, dtype=np.float32).reshape(dst.shape)
+
+    vertices_mutable = verts_mutable
+
+    @property
+    def faces_mutable(self):
+        return self._mutable("faces")
+
+    @faces_mutable.setter
+    def faces_mutable(self, val):
+        dst = self._mutable("faces")
+        dst[...] = np.asarray(val, dtype=np.uint32).reshape(dst.shape)
+
+    def __repr__(self):  # pybind.cpp:157-161 (the reference's string has this unbalanced bracket)
+        return f"<sdf.Renderer(verts.shape=({self._nv}, 3), faces.shape=({self._nf}, 3)>"

@@ -276,3 +276,19 @@ def test_cpp_facade_runs_on_gpu(tmp_path):
                            "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_robust_handle_without_faces():
+    """vertices only (nf = 0), robust: the parity rays find an empty grid cell; every vertex is
+    isolated -> sqrt(FLT_MAX) with the ray sign (sdf.cpp:146-148)"""
+    rng = np.random.default_rng(4)
+    v = rng.uniform(-0.5, 0.5, (300, 3)).astype(np.float32)
+    f = np.zeros((0, 3), np.uint32)
+    R = meshes.random_rotation(1)
+    s = SDF(v, f, robust=True)
+    s.set_raycast_axes(R)
+    o = po.OracleSDF(v, f, True, R)
+    for n in (2000, 20000):  # strict kernel / packet kernel
+        p = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+        assert not s.contains(p).any()
+        assert (s.nn(p) == o.nn(p)).all() and same_float(s(p), o(p)).all()
