@@ -1,5 +1,5 @@
-// sdf_amd/sdf.hpp — C++ façade with the reference's `sdf::SDF` surface
-// (include/sdf/sdf.hpp:150-258 of sxyu/sdf) over the C ABI of sdfhip.h.
+// sdf_amd/sdf.hpp — C++ façade with the reference's `sdf::SDF` and `sdf::Renderer` surfaces
+// (include/sdf/sdf.hpp:150-258, 282-369 of sxyu/sdf) over the C ABI of sdfhip.h.
 //
 // Two spellings of every method:
 //   * plain-pointer / std::vector signatures: always available;
@@ -219,6 +219,145 @@ struct SDF {
         if (rc != 0) throw std::runtime_error(std::string("sdfhip: ") + sdfhip_last_error());
     }
     sdfhip_t* h_ = nullptr;
+};
+
+// sdf::Renderer (sdf.hpp:282-369 of the reference, src/renderer.cpp): image-space raycaster.
+// Images are row-major [height, width]; image points are row-major [n, 2] (x, y).
+struct Renderer {
+    Renderer(const float* verts, uint32_t n_verts, const Index* faces, uint32_t n_faces, int width = 1080,
+             int height = 1080, float fx = 2600.f, float fy = 2600.f, float cx = 540.f, float cy = 540.f,
+             bool copy = false, int device = -1)
+        : own_data(copy) {
+        check(sdfhip_renderer_create(verts, n_verts, faces, n_faces, width, height, fx, fy, cx, cy,
+                                     copy ? 1 : 0, device, &h_));
+    }
+#ifdef SDF_AMD_HAVE_EIGEN
+    using Points2D = Eigen::Matrix<float, Eigen::Dynamic, 2, Eigen::RowMajor>;  // sdf.hpp:45
+    // sdf.hpp:298-301
+    Renderer(Eigen::Ref<const Points> verts, Eigen::Ref<const Triangles> faces, int width = 1080,
+             int height = 1080, float fx = 2600.f, float fy = 2600.f, float cx = 540.f, float cy = 540.f,
+             bool copy = false)
+        : Renderer(verts.data(), (uint32_t)verts.rows(), faces.data(), (uint32_t)faces.rows(), width, height,
+                   fx, fy, cx, cy, copy) {}
+#endif
+    ~Renderer() { sdfhip_renderer_destroy(h_); }
+    Renderer(const Renderer&) = delete;
+    Renderer& operator=(const Renderer&) = delete;
+
+    /*** PRIMARY INTERFACE (sdf.hpp:306-344) ***/
+    std::vector<float> render_depth_vec(int /*n_threads*/ = 0) const {
+        std::vector<float> out((size_t)width() * height());
+        check(sdfhip_renderer_render_depth(h_, out.data()));
+        return out;
+    }
+    std::vector<uint8_t> render_mask_vec(int /*n_threads*/ = 0) const {
+        std::vector<uint8_t> out((size_t)width() * height());
+        check(sdfhip_renderer_render_mask(h_, out.data()));
+        return out;
+    }
+    std::vector<int> render_nn_vec(bool fill_outside = false, int /*n_threads*/ = 0) const {
+        std::vector<int> out((size_t)width() * height());
+        check(sdfhip_renderer_render_nn(h_, fill_outside ? 1 : 0, out.data()));
+        return out;
+    }
+    std::vector<float> operator()(const float* points2, int64_t n, int /*n_threads*/ = 0) const {
+        std::vector<float> out((size_t)n);
+        check(sdfhip_renderer_depth(h_, points2, n, out.data()));
+        return out;
+    }
+    std::vector<uint8_t> contains(const float* points2, int64_t n, int /*n_threads*/ = 0) const {
+        std::vector<uint8_t> out((size_t)n);
+        check(sdfhip_renderer_contains(h_, points2, n, out.data()));
+        return out;
+    }
+    std::vector<int> nn(const float* points2, int64_t n, bool fill_outside = false, int /*n_threads*/ = 0) const {
+        std::vector<int> out((size_t)n);
+        check(sdfhip_renderer_nn(h_, points2, n, fill_outside ? 1 : 0, out.data()));
+        return out;
+    }
+    // device pointers on `stream` (hipStream_t); kind 0 depth, 1 mask, 2 vertex id; d_points2 may be
+    // null (image pixels)
+    void query_device(int kind, const float* d_points2, int64_t n, bool fill_outside, void* d_out,
+                      void* stream) const {
+        check(sdfhip_renderer_query_device(h_, kind, d_points2, n, fill_outside ? 1 : 0, d_out, stream));
+    }
+#ifdef SDF_AMD_HAVE_EIGEN
+    Eigen::Matrix<float, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> render_depth(
+        int /*n_threads*/ = std::thread::hardware_concurrency()) const {
+        Eigen::Matrix<float, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> out(height(), width());
+        check(sdfhip_renderer_render_depth(h_, out.data()));
+        return out;
+    }
+    Eigen::Matrix<bool, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> render_mask(
+        int /*n_threads*/ = std::thread::hardware_concurrency()) const {
+        Eigen::Matrix<bool, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> out(height(), width());
+        check(sdfhip_renderer_render_mask(h_, reinterpret_cast<uint8_t*>(out.data())));
+        return out;
+    }
+    Eigen::Matrix<int, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> render_nn(
+        bool fill_outside = false, int /*n_threads*/ = std::thread::hardware_concurrency()) const {
+        Eigen::Matrix<int, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> out(height(), width());
+        check(sdfhip_renderer_render_nn(h_, fill_outside ? 1 : 0, out.data()));
+        return out;
+    }
+    Vector operator()(Eigen::Ref<const Points2D> points,
+                      int /*n_threads*/ = std::thread::hardware_concurrency()) const {
+        Vector out(points.rows());
+        check(sdfhip_renderer_depth(h_, points.data(), points.rows(), out.data()));
+        return out;
+    }
+    Eigen::Matrix<bool, Eigen::Dynamic, 1> contains(
+        Eigen::Ref<const Points2D> points, int /*n_threads*/ = std::thread::hardware_concurrency()) const {
+        Eigen::Matrix<bool, Eigen::Dynamic, 1> out(points.rows());
+        check(sdfhip_renderer_contains(h_, points.data(), points.rows(), reinterpret_cast<uint8_t*>(out.data())));
+        return out;
+    }
+    Eigen::VectorXi nn(Eigen::Ref<const Points2D> points, bool fill_outside = false,
+                       int /*n_threads*/ = std::thread::hardware_concurrency()) const {
+        Eigen::VectorXi out(points.rows());
+        check(sdfhip_renderer_nn(h_, points.data(), points.rows(), fill_outside ? 1 : 0, out.data()));
+        return out;
+    }
+#endif
+    void update() { check(sdfhip_renderer_update(h_)); }  // sdf.hpp:344
+
+    /*** DATA ACCESSORS (sdf.hpp:346-356) ***/
+    int width() const { return sdfhip_renderer_width(h_); }
+    int height() const { return sdfhip_renderer_height(h_); }
+    uint32_t num_verts() const { return sdfhip_renderer_num_verts(h_); }
+    uint32_t num_faces() const { return sdfhip_renderer_num_faces(h_); }
+    const float* verts_data() const { return sdfhip_renderer_verts(h_); }
+    const Index* faces_data() const { return sdfhip_renderer_faces(h_); }
+    float* verts_mutable_data() {  // renderer.cpp:298-304
+        if (!own_data) std::cerr << "ERROR: 'verts' is non mutable, construct with copy=True\n";
+        return sdfhip_renderer_verts_mutable(h_);
+    }
+    Index* faces_mutable_data() {  // renderer.cpp:289-295
+        if (!own_data) std::cerr << "ERROR: 'faces' is non mutable, construct with copy=True\n";
+        return sdfhip_renderer_faces_mutable(h_);
+    }
+#ifdef SDF_AMD_HAVE_EIGEN
+    Eigen::Map<const Triangles> faces() const { return {faces_data(), (Eigen::Index)num_faces(), 3}; }
+    Eigen::Map<const Points> verts() const { return {verts_data(), (Eigen::Index)num_verts(), 3}; }
+    Eigen::Map<Points> verts_mutable() {
+        float* p = verts_mutable_data();
+        return {p, p ? (Eigen::Index)num_verts() : 0, 3};
+    }
+    Eigen::Map<Triangles> faces_mutable() {
+        Index* p = faces_mutable_data();
+        return {p, p ? (Eigen::Index)num_faces() : 0, 3};
+    }
+#endif
+
+    const bool own_data;  // sdf.hpp:356
+
+    sdfhip_renderer_t* handle() const { return h_; }
+
+   private:
+    static void check(int rc) {
+        if (rc != 0) throw std::runtime_error(std::string("sdfhip: ") + sdfhip_last_error());
+    }
+    sdfhip_renderer_t* h_ = nullptr;
 };
 
 }  // namespace sdf
