@@ -146,6 +146,9 @@ typedef struct {
     int64_t query_kernel_points;
     /* queries of the last packet-kernel launch that were deferred to the strict kernel */
     int64_t last_fallback_points;
+    /* queries of the last call whose wave exceeded its work budget in the packet pass and were
+     * answered by the one-wave-per-query kernel (option "heavy_budget") */
+    int64_t last_heavy_points;
 } sdfhip_stats_t;
 int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* out);
 
@@ -209,7 +212,8 @@ int sdfhip_host_free(void* p);
 
 /* Tuning knobs (no counterpart). key: "sort_queries" (0/1, default 1: Morton-sort query
  * chunks of >= sort_min points), "sort_min", "chunk" (points per internal chunk), "packet" (0: strict kernel only),
- * "fast_nn" (0/1, applies at the next update: the vertex tree is built on the GPU, no host kd-tree;
+ * "heavy_budget" (chunks of four vertices a wave of the packet pass may evaluate before its queries go
+ * to the one-wave-per-query kernel; 0 = automatic: 1/8 of the tree), "fast_nn" (0/1, applies at the next update: the vertex tree is built on the GPU, no host kd-tree;
  * distances stay exact, an exact fp32 distance tie goes to the lowest (Morton code, index) vertex instead of the
  * reference's first-visited one), "packet_group" (vertices per leaf group of the packet pass, 10..60, applies at the next update), "host_chunk" (points per
  * staging slot of the host entry points, 0 = automatic),

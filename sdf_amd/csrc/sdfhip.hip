@@ -88,6 +88,8 @@ struct MeshDev {
     float bb[6];  // mesh AABB == kd root bbox
     // packet traversal extras: vertices padded to 16 B, ambiguity factors c = 1 + W and ~c^2
     const float4* kd_pts4;
+    uint32_t kd_npos;       // padded tree positions (sentinel slots included)
+    uint32_t heavy_budget;  // packet pass: a wave that has evaluated more chunks than this gives up
     float amb_c, amb_c2;
     // adjacency + face geometry
     const uint32_t* adj_off;
@@ -586,6 +588,7 @@ struct PacketBest {
     float b;     // global fp32 minimum over all vertices
     float s;     // second smallest distance as a multiset (an exact tie shows as s == b); exact
                  // whenever it is <= b * c^2
+    bool bailed;  // the wave exceeded its work budget: nothing is valid, see k_query_heavy
     uint32_t h;  // among the vertices at distance exactly b, the one nanoflann's near-first DFS
                  // (for THIS lane) meets first: its tree position, or (bit 31) the ref of the
                  // packet group in which it is the only vertex at that distance; H_NONE: none
@@ -647,6 +650,14 @@ struct PacketStack {
     uint32_t* ref;  // [level]
 };
 
+#ifdef SDFK_STATS
+// tuning build only (make stats): per-wave work counters of the packet pass
+__device__ unsigned long long g_pk_stats[8];  // waves, quad nodes, groups, chunks, tie redos, pops, pushes
+#define SDFK_COUNT(K, V) if ((threadIdx.x & 63) == 0) atomicAdd(&g_pk_stats[K], (unsigned long long)(V))
+#else
+#define SDFK_COUNT(K, V)
+#endif
+
 __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float qx, float qy, float qz,
                                                         const PacketStack stk) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -658,10 +669,13 @@ __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float 
     const float c = M.amb_c2;  // everything within best * c^2 is evaluated
     uint32_t cur = M.kd_qroot;
     uint32_t sp = 0;
+    uint32_t work = 0;  // chunks evaluated so far (wave-uniform)
+    SDFK_COUNT(0, 1);
     for (;;) {
         cur = __builtin_amdgcn_readfirstlane(cur);
         bool need_pop = false;
         if (!(cur & KD_LEAF)) {
+            SDFK_COUNT(1, 1);
             // 4-wide node: boxes and child refs by scalar loads; slots 0,1 / 2,3 are the two
             // binary sides
             const float* Q = (const float*)(M.kd_qn + 8 * (size_t)cur);
@@ -722,17 +736,36 @@ __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float 
             const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
             const float4* P = M.kd_pts4 + first;
             const uint32_t b0 = b, s0 = s2, h0 = h;
+            // Tail limiter.  A wave whose queries sit near a centre of symmetry of the mesh (the
+            // middle of a sphere) needs most of the tree, one dependent scalar load after the
+            // other: ~0.3 us per chunk, 12 ms for 180k vertices, and the launch cannot end before
+            // it does.  Past the budget the wave hands its queries to k_query_heavy (one wave
+            // per query, lanes over the vertices).
+            work += nch;
+            SDFK_COUNT(2, 1);
+            SDFK_COUNT(3, nch);
             if (nch) {
                 const u32x16* C = (const u32x16*)__builtin_assume_aligned(P, 64);
+#ifdef SDFK_PREFETCH
+                // one chunk ahead: the load of chunk ci + 1 is in flight while chunk ci is evaluated
+                u32x16 A = C[0];
+                for (uint32_t ci = 0; ci < nch; ++ci) {
+                    const u32x16 N = C[ci + 1 < nch ? ci + 1 : ci];
+                    SDFK_PACKET_CHUNK(A)
+                    A = N;
+                }
+#else
                 for (uint32_t ci = 0; ci < nch; ++ci) {
                     const u32x16 A = C[ci];
                     SDFK_PACKET_CHUNK(A)
                 }
+#endif
                 if (b != b0) h = cur;  // strictly improved here: the holder is in this group
                 if (__ballot(s2 == b) != 0ull) {
                     // rare: some lane's two smallest distances are equal.  Redo the group for
                     // the wave in ascending position and settle each exact tie by DFS order.
                     b = b0, s2 = s0, h = h0;
+                    SDFK_COUNT(4, 1);
                     for (uint32_t k = 0; k < 4u * nch; ++k) {
                         const float4 Qp = P[k];
                         const float dx = qx - Qp.x, dy = qy - Qp.y, dz = qz - Qp.z;
@@ -760,12 +793,15 @@ __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float 
         }
         if (need_pop) {
             const uint32_t thr16 = __float_as_uint(__uint_as_float(b) * c) >> 16;
+            const bool over = work > M.heavy_budget;  // give up: drop what is still on the stack
+            if (over) sp = 0;
             for (;;) {
                 if (sp == 0) {
                     if (b == tieb) s2 = b;
-                    return PacketBest{__uint_as_float(b), __uint_as_float(s2), h};
+                    return PacketBest{__uint_as_float(b), __uint_as_float(s2), over, h};
                 }
                 --sp;
+                SDFK_COUNT(5, 1);
                 const uint32_t l16 = stk.lb[sp * 64u + lane];
                 const uint32_t r = stk.ref[sp];
                 if (__ballot(l16 <= thr16) != 0ull) {
@@ -838,7 +874,9 @@ __global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float*
                                                          int trunc_aabb, void* __restrict__ out,
                                                          unsigned long long* __restrict__ amb_mask,
                                                          uint32_t* __restrict__ amb_cnt,
-                                                         uint32_t depth_cap) {
+                                                         uint32_t depth_cap, uint32_t off,
+                                                         uint32_t* __restrict__ heavy_list,
+                                                         uint32_t* __restrict__ heavy_cnt) {
     extern __shared__ uint32_t lds[];
     // per wave: depth_cap rows of 64 x u16 lower bounds, then depth_cap refs
     PacketStack stk;
@@ -859,6 +897,19 @@ __global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float*
         return;
     }
     const PacketBest pb = kd_nearest_packet(M, p.x, p.y, p.z, stk);
+    if (pb.bailed) {  // wave-uniform: every query of this wave goes to the heavy list (absolute indices)
+        const unsigned long long vm = __ballot(valid);
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if (lane == 0) {
+            base = atomicAdd(heavy_cnt, (uint32_t)__popcll(vm));
+            amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        if (valid) heavy_list[base + (uint32_t)__popcll(vm & lt)] = off + (uint32_t)src;
+        return;
+    }
     // pb.h is nanoflann's answer iff nanoflann does not prune it before visiting it:
     //  (1) no other vertex within b * c (c - 1 ~ 4.5e-6): impossible, see k_query_packet header;
     //  (2) otherwise measure it: every bound tested on the way to pb.h is <= the distance of
@@ -869,6 +920,9 @@ __global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float*
     if (!M.fast) {
         if (valid && (!(pb.s > pb.b * M.amb_c) || !(pb.b >= 1e-30f))) {
             amb = true;
+#ifdef SDFK_STATS
+            atomicAdd(&g_pk_stats[6], 1ull);
+#endif
             if (pos >= 0 && pb.b < FLT_MAX) {
                 const float mb = kd_path_max_bound(M, p.x, p.y, p.z, pos);
                 amb = !(mb <= pb.s);
@@ -879,6 +933,7 @@ __global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float*
     {   // ambiguous lanes of this wave, in sorted order: compacted (stably) by k_fb_compact so
         // that the strict fallback kernel still sees Morton-coherent waves
         const unsigned long long m = __ballot(valid && amb);
+        SDFK_COUNT(7, __popcll(m));
         if ((threadIdx.x & 63) == 0) {
             amb_mask[i >> 6] = m;
             amb_cnt[i >> 6] = (uint32_t)__popcll(m);
@@ -914,6 +969,135 @@ __global__ void k_fb_compact(const unsigned long long* __restrict__ amb_mask,
     const uint32_t base = *base_in + amb_scan[w];
     if ((m >> lane) & 1ull) fb_list[base + (uint32_t)__popcll(m & lt)] = off + perm[i];
     if (i == n - 1) *total_out = base + (uint32_t)__popcll(m);
+}
+
+// The queries of the waves that gave up in the packet pass: ONE WAVE PER QUERY, the 64 lanes
+// stride over all (padded) tree positions — no pruning, no dependent loads, V / 64 steps.  The
+// (four queries per pass share each vertex load).  The same three things come out as from the packet pass: the exact fp32 minimum b, the second
+// smallest distance s as a multiset (always exact here), and h = among the vertices at distance
+// exactly b the one nanoflann's DFS meets first (folded pairwise with kd_dfs_first, a total order
+// for a fixed query; fast_nn: the lowest position).  Then the packet kernel's own decision:
+// window test, path check, else defer to the strict kernel's list.
+constexpr int HEAVY_Q = 4;  // queries per wave pass: one vertex load serves four distance evaluations
+template <int KIND, bool ROBUST>
+__global__ __launch_bounds__(256) void k_query_heavy(MeshDev M, const float* __restrict__ pts,
+                                                     const uint32_t* __restrict__ heavy_list,
+                                                     const uint32_t* __restrict__ heavy_cnt, int trunc_aabb,
+                                                     void* __restrict__ out, uint32_t* __restrict__ fb_list,
+                                                     uint32_t* __restrict__ fb_cnt) {
+    const uint32_t cnt = *heavy_cnt;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t q0 = HEAVY_Q * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6); q0 < cnt; q0 += HEAVY_Q * nw) {
+        uint32_t src[HEAVY_Q], b[HEAVY_Q], s2[HEAVY_Q], h[HEAVY_Q];
+        V3 p[HEAVY_Q];
+#pragma unroll
+        for (int j = 0; j < HEAVY_Q; ++j) {
+            const uint32_t q = q0 + j < cnt ? q0 + j : cnt - 1;  // the tail repeats the last query
+            src[j] = heavy_list[q];
+            p[j] = {pts[3 * (size_t)src[j]], pts[3 * (size_t)src[j] + 1], pts[3 * (size_t)src[j] + 2]};
+            b[j] = 0x7F7FFFFFu, s2[j] = 0x7F7FFFFFu, h[j] = H_NONE;
+        }
+        // four positions per step, their loads issued together (the loop is latency bound
+        // otherwise).  Uniform trip count and no branch in the body: a position past the end reads
+        // the last slot and gets the distance 0xFFFFFFFF, which changes nothing.
+        for (uint32_t k0 = 0; k0 < M.kd_npos; k0 += 256u) {
+            float4 P[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t k = k0 + 64u * u + lane;
+                P[u] = M.kd_pts4[k < M.kd_npos ? k : M.kd_npos - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t k = k0 + 64u * u + lane;
+#pragma unroll
+                for (int j = 0; j < HEAVY_Q; ++j) {
+                    const float dx = p[j].x - P[u].x, dy = p[j].y - P[u].y, dz = p[j].z - P[u].z;
+                    uint32_t du = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+                    du = k < M.kd_npos ? du : 0xFFFFFFFFu;
+                    // branch-free: on du == b the earlier (lower) position stays, s2 = b flags the tie
+                    const bool lt = du < b[j];
+                    s2[j] = lt ? b[j] : min(s2[j], du);
+                    h[j] = lt ? k : h[j];
+                    b[j] = min(b[j], du);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < HEAVY_Q; ++j) {
+            for (int o = 32; o >= 1; o >>= 1) {
+                const uint32_t ob = __shfl_xor(b[j], o), os = __shfl_xor(s2[j], o), oh = __shfl_xor(h[j], o);
+                const uint32_t nh = ob < b[j] ? oh : (b[j] < ob ? h[j] : min(h[j], oh));  // H_NONE is the largest
+                s2[j] = min(min(s2[j], os), max(b[j], ob));
+                b[j] = min(b[j], ob);
+                h[j] = nh;
+            }
+            // Exact tie (wave-uniform after the reduction): h is the lowest tied position, which is
+            // the fast_nn rule; nanoflann's rule wants the tied vertex its DFS meets first: second
+            // scan over the vertices at distance exactly b, folded with kd_dfs_first (a total
+            // order for a fixed query).  Kept out of the main loop: one tree walk per tied vertex.
+            if (s2[j] == b[j] && h[j] != H_NONE && !M.fast) {
+                uint32_t hh = H_NONE;
+                for (uint32_t k0 = 0; k0 < M.kd_npos; k0 += 256u) {
+                    uint32_t du[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t k = k0 + 64u * u + lane;
+                        const float4 P = M.kd_pts4[k < M.kd_npos ? k : M.kd_npos - 1];
+                        const float dx = p[j].x - P.x, dy = p[j].y - P.y, dz = p[j].z - P.z;
+                        du[u] = k < M.kd_npos ? __float_as_uint((dx * dx + dy * dy) + dz * dz) : 0xFFFFFFFFu;
+                    }
+                    if (__ballot(du[0] == b[j] || du[1] == b[j] || du[2] == b[j] || du[3] == b[j]) == 0ull) continue;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t k = k0 + 64u * u + lane;
+                        if (du[u] == b[j])
+                            hh = hh == H_NONE ? k : (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)hh, (int)k);
+                    }
+                }
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const uint32_t oh = __shfl_xor(hh, o);
+                    if (hh == H_NONE)
+                        hh = oh;
+                    else if (oh != H_NONE)
+                        hh = (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)hh, (int)oh);
+                }
+                h[j] = hh;
+            }
+        }
+        // lane j finishes query j
+        if (lane >= (uint32_t)HEAVY_Q || q0 + lane >= cnt) continue;
+        uint32_t mb = b[0], ms = s2[0], mh = h[0], msrc = src[0];
+        V3 mp = p[0];
+#pragma unroll
+        for (int j = 1; j < HEAVY_Q; ++j)
+            if (lane == (uint32_t)j) mb = b[j], ms = s2[j], mh = h[j], msrc = src[j], mp = p[j];
+        const int pos = mh == H_NONE ? -1 : (int)mh;
+        const float bf = __uint_as_float(mb), sf = __uint_as_float(ms);
+        bool amb = false;
+        if (!M.fast) {
+            if (!(sf > bf * M.amb_c) || !(bf >= 1e-30f)) {
+                amb = true;
+                if (pos >= 0 && bf < FLT_MAX) amb = !(kd_path_max_bound(M, mp.x, mp.y, mp.z, pos) <= sf);
+            }
+            if (pos < 0) amb = true;
+        }
+        if (amb) {
+            fb_list[atomicAdd(fb_cnt, 1u)] = msrc;
+        } else if (KIND == Q_NN) {
+            ((int32_t*)out)[msrc] = pos >= 0 ? M.kd_vind[pos] : -1;
+        } else {
+            float sign = 0.f;
+            if (ROBUST) sign = raycast(M, mp, nullptr);
+            const bool trunc = (KIND == Q_CONTAINS) ? true : (trunc_aabb != 0);
+            const float v = calc_tail<ROBUST>(M, mp, trunc, sign, pos);
+            if (KIND == Q_CONTAINS)
+                ((uint8_t*)out)[msrc] = v >= 0;
+            else
+                ((float*)out)[msrc] = v;
+        }
+    }
 }
 
 // =========================================================================================
@@ -1664,6 +1848,8 @@ struct sdfhip_ctx {
     uint32_t* d_fb_count = nullptr;  // two words, ping-pong (see k_fb_compact)
     int64_t fb_cap = 0;
     uint32_t last_fb = 0;  // length of the last deferred list (read back only while profiling)
+    uint32_t last_heavy = 0;  // queries of the last call's heavy waves (same)
+    int64_t opt_heavy_budget = 0;  // chunks per wave before it gives up; 0 = automatic
     unsigned long long* d_amb_mask = nullptr;
     uint32_t* d_amb_cnt = nullptr;
     uint32_t* d_amb_s1 = nullptr;
@@ -2124,6 +2310,11 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.kd_root = h->fast_active ? KD_LEAF : h->kd.root_ref;
     for (int d = 0; d < 6; ++d) M.bb[d] = h->aabb[d];
     M.kd_pts4 = h->d_kd_pts4;
+    M.kd_npos = h->fast_active ? (uint32_t)(FAST_GROUP * ((h->nv + FAST_GROUP - 1) / FAST_GROUP))
+                               : (uint32_t)h->kd.pos_vert.size();
+    // a wave may walk 1/8 of the tree (4 positions per chunk) before it hands its queries over
+    M.heavy_budget = h->opt_heavy_budget > 0 ? (uint32_t)h->opt_heavy_budget
+                                             : (M.kd_npos / 32u > 4096u ? M.kd_npos / 32u : 4096u);
     M.amb_c = h->amb_c;
     M.amb_c2 = h->amb_c2;
     M.adj_off = h->d_adj_off;
@@ -2214,8 +2405,8 @@ int reserve_query_ws(sdfhip_ctx* h, int64_t n, int64_t fb_cap) {
             if (int rc = dalloc(&h->d_qbounds, 8)) return rc;
         h->q_cap = n;
     }
-    if (fb_cap > h->fb_cap) {
-        if (int rc = dalloc(&h->d_fb_list, (size_t)fb_cap)) return rc;
+    if (fb_cap > h->fb_cap) {  // [0, cap): deferred near-tie queries; [cap, 2 cap): heavy-wave queries
+        if (int rc = dalloc(&h->d_fb_list, 2 * (size_t)fb_cap)) return rc;
         h->fb_cap = fb_cap;
     }
     return 0;
@@ -2239,21 +2430,36 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     const uint32_t pstack = 3u * (uint32_t)(qdepth > 0 ? qdepth : 1) + 4u;
     const bool packet_any =
         KIND != Q_DETAIL && (fast || (sort_any && h->opt_packet && pstack * 132u <= 48u * 1024u));
-    const int64_t fb_cap = packet_any && !fast ? (n < (1ll << 27) ? n : (1ll << 27)) : 0;
+    const int64_t fb_cap = packet_any ? (n < (1ll << 27) ? n : (1ll << 27)) : 0;
     if (sort_any || fast)
         if (int rc = reserve_query_ws(h, n < chunk ? n : chunk, fb_cap)) return rc;
     int64_t deferred_pts = 0;  // points whose near ties may sit in the deferred list
     int flip = 0;              // d_fb_count[flip] holds the current list length
-    if (packet_any) HIPC(hipMemsetAsync(h->d_fb_count, 0, 2 * sizeof(uint32_t), s));
+    // d_fb_count: [0], [1] length of the deferred list (ping-pong), [2] length of the heavy list
+    if (packet_any) HIPC(hipMemsetAsync(h->d_fb_count, 0, 3 * sizeof(uint32_t), s));
     auto flush = [&]() -> int {
         if (deferred_pts == 0) return 0;
-        const int64_t grid_pts = deferred_pts < (int64_t)QBLOCK * 4096 ? deferred_pts : (int64_t)QBLOCK * 4096;
-        if (int rc = launch_strict<KIND, ROBUST>(h, M, d_pts, h->d_fb_list, grid_pts, trunc, d_out,
-                                                 h->d_fb_count + flip, s))
-            return rc;
-        if (h->opt_profile)
+        constexpr int HK = (KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST)) ? Q_NN : KIND;
+        if (!(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST))) {
+            // queries of the waves that gave up (tail limiter): one wave per query; what is
+            // still ambiguous afterwards joins the deferred list
+            const int64_t hw = deferred_pts < 8192 ? deferred_pts : 8192;
+            k_query_heavy<HK, ROBUST><<<(uint32_t)((hw + 3) / 4), 256, 0, s>>>(
+                M, d_pts, h->d_fb_list + h->fb_cap, h->d_fb_count + 2, trunc, d_out, h->d_fb_list,
+                h->d_fb_count + flip);
+            HIPC(hipGetLastError());
+        }
+        if (!fast) {
+            const int64_t grid_pts = deferred_pts < (int64_t)QBLOCK * 4096 ? deferred_pts : (int64_t)QBLOCK * 4096;
+            if (int rc = launch_strict<KIND, ROBUST>(h, M, d_pts, h->d_fb_list, grid_pts, trunc, d_out,
+                                                     h->d_fb_count + flip, s))
+                return rc;
+        }
+        if (h->opt_profile) {
             HIPC(hipMemcpyAsync(&h->last_fb, h->d_fb_count + flip, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPC(hipMemsetAsync(h->d_fb_count, 0, 2 * sizeof(uint32_t), s));
+            HIPC(hipMemcpyAsync(&h->last_heavy, h->d_fb_count + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        }
+        HIPC(hipMemsetAsync(h->d_fb_count, 0, 3 * sizeof(uint32_t), s));
         flip = 0;
         deferred_pts = 0;
         return 0;
@@ -2275,17 +2481,19 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             perm = sorted_perm;
         }
         if (packet_any && (perm || fast)) {
-            if (!fast && deferred_pts + m > h->fb_cap)
+            if (deferred_pts + m > h->fb_cap)
                 if (int rc = flush()) return rc;
             const size_t lds = (size_t)(PBLOCK / 64) * pstack * 33u * sizeof(uint32_t);
             constexpr int PK = KIND == Q_DETAIL ? Q_NN : KIND;
             ProfScope prof{h, s};  // the dominant kernel, one event pair per launch
             if (int rc = prof.begin()) return rc;
             k_query_packet<PK, ROBUST><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, lds, s>>>(
-                M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, pstack);
+                M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, pstack, (uint32_t)off,
+                h->d_fb_list + h->fb_cap, h->d_fb_count + 2);
             if (int rc = prof.end(m)) return rc;
-            if (fast) {  // nothing is ever deferred
+            if (fast) {  // no near-tie deferral in this mode, only the heavy list
                 HIPC(hipGetLastError());
+                deferred_pts += m;
                 continue;
             }
             exclusive_scan_u32(h->d_amb_cnt, (uint32_t)((m + 63) / 64), h->d_amb_s1, h->d_amb_s2, s);
@@ -2583,7 +2791,7 @@ int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32
         rc = fail(SDFHIP_E_HIP, "hipStreamCreate failed");
     A(dalloc(&h->d_verts, 3 * (size_t)nv));
     A(dalloc(&h->d_faces, 3 * (size_t)nf));
-    A(dalloc(&h->d_fb_count, 2));
+    A(dalloc(&h->d_fb_count, 4));
     A(dalloc(&h->d_adj_off, (size_t)nv + 1));
     A(dalloc(&h->d_adj_faces, 3 * (size_t)nf));
     A(dalloc(&h->d_geo, 4 * (size_t)nf));
@@ -2803,9 +3011,11 @@ int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* o) {
     o->query_kernel_launches = h->prof_launches;
     o->query_kernel_points = h->prof_points;
     o->last_fallback_points = 0;
+    o->last_heavy_points = 0;
     if (h->d_fb_count) {
         DevGuard g(h->device);
         o->last_fallback_points = h->last_fb;
+        o->last_heavy_points = h->last_heavy;
     }
     return 0;
 }
@@ -2835,6 +3045,17 @@ int sdfhip_sample_surface(sdfhip_t* h, int64_t n, uint64_t seed, float* out) {
     (void)hipFree(d);
     return rc;
 }
+#ifdef SDFK_STATS
+int sdfhip_debug_packet_stats(unsigned long long out[8], int reset) {
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_stats), 8 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIPC(hipMemcpyToSymbol(HIP_SYMBOL(g_pk_stats), z, sizeof(z)));
+    }
+    return 0;
+}
+#endif
 int sdfhip_host_alloc(size_t bytes, void** out) {
     if (!out) return fail(SDFHIP_E_INVALID, "out is null");
     *out = nullptr;
@@ -2864,7 +3085,10 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_build_threads = v < 1 ? 1 : v;
     else if (!strcmp(key, "packet"))
         h->opt_packet = v;
-    else if (!strcmp(key, "fast_nn"))
+    else if (!strcmp(key, "heavy_budget")) {
+        if (v < 0 || v > 0x7FFFFFFF) return fail(SDFHIP_E_INVALID, "heavy_budget must be >= 0 (0 = automatic)");
+        h->opt_heavy_budget = v;
+    } else if (!strcmp(key, "fast_nn"))
         h->opt_fast_nn = v ? 1 : 0;  // takes effect at the next sdfhip_update
     else if (!strcmp(key, "ray_mode")) {
         if (v < 0 || v > 2) return fail(SDFHIP_E_INVALID, "ray_mode must be 0 (auto), 1 (grid) or 2 (LBVH)");

@@ -39,7 +39,7 @@ class _Stats(C.Structure):
                 ("bvh_depth", C.c_int32), ("last_update_ms", C.c_float),
                 ("last_kd_build_ms", C.c_float), ("query_kernel_ms", C.c_double),
                 ("query_kernel_launches", C.c_int64), ("query_kernel_points", C.c_int64),
-                ("last_fallback_points", C.c_int64)]
+                ("last_fallback_points", C.c_int64), ("last_heavy_points", C.c_int64)]
 
 
 _lib = None

@@ -169,3 +169,25 @@ def test_page_locked_host_arrays_and_out_argument():
         s(pts, out=np.empty(n, np.float64))
     o = po.OracleSDF(v, f, True, R)
     assert same_float(od[:100000], o(pts[:100000])).all()
+
+
+def test_config4_icosphere7_variant_oracle_sample():
+    """BASELINE config 4's second mesh: icosphere subdiv-7 (163,842 v / 327,680 f),
+    radius 0.8 with 5 % seeded radial noise; robust, random points; oracle on a sample."""
+    v, f = meshes.icosphere(7, radius=0.8, noise=0.05, seed=3)
+    assert v.shape[0] == 163_842 and f.shape[0] == 327_680
+    R = meshes.random_rotation(1234)
+    s = SDF(v, f, robust=True)
+    s.set_raycast_axes(R)
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-1, 1, (4_000_000, 3)).astype(np.float32)
+    d, c, n = s(pts), s.contains(pts), s.nn(pts)
+    assert ((d > 0) == c)[d != 0].all()
+    rad = np.linalg.norm(pts, axis=1)
+    rv = np.linalg.norm(v, axis=1)  # the noise is radial: star-shaped around the origin
+    assert c[rad < rv.min() * 0.98].all() and not c[rad > rv.max()].any()
+    k = 250_000
+    o = po.OracleSDF(v, f, True, R)
+    assert (n[:k] == o.nn(pts[:k])).all()
+    assert (c[:k] == o.contains(pts[:k])).all()
+    assert same_float(d[:k], o(pts[:k])).all()

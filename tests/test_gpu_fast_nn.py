@@ -155,3 +155,21 @@ def test_non_finite_and_huge_query_points_terminate(fast):
         assert (c[batch_ok] == o.contains(fin)).all()
         assert ((n >= -1) & (n < v.shape[0])).all()
         assert not c[~batch_ok][np.isfinite(batch[~batch_ok]).all(1)].any()  # 1e30: outside the AABB
+
+
+def test_fast_nn_heavy_wave_path_forced():
+    g = load_golden("teapot")
+    v, f = g["verts"], g["faces"]
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.uniform(-1, 1, (60000, 3)), meshes.grid_points(24)]).astype(np.float32)
+    s = SDF(v, f, robust=False)
+    s.set_option("fast_nn", 1)
+    s.update()
+    want = s.nn(pts)
+    assert (want[:15000] == _fast_rule_bruteforce(v, pts[:15000])).all()
+    d = s(pts)
+    s.set_option("heavy_budget", 1)
+    s.set_option("profile", 1)
+    assert (s.nn(pts) == want).all()
+    assert s.stats["last_heavy_points"] > pts.shape[0] // 2
+    assert same_float(s(pts), d).all()

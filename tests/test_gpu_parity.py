@@ -292,3 +292,59 @@ def test_robust_handle_without_faces():
         p = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
         assert not s.contains(p).any()
         assert (s.nn(p) == o.nn(p)).all() and same_float(s(p), o(p)).all()
+
+
+@pytest.mark.parametrize("budget", [1, 40])
+def test_heavy_wave_path_forced(budget):
+    """tail limiter of the packet pass: with a tiny work budget every wave (budget 1) or the long
+    ones (budget 40) hand their queries to the one-wave-per-query kernel; results must not move.
+    Covers unique minimisers, near ties (path check), exact ties (DFS fold) and the sdf tail."""
+    rng = np.random.default_rng(21)
+    # (a) tie-heavy lattice, non-robust
+    g = np.stack(np.meshgrid(*[np.arange(-6, 7)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    v = (g[rng.permutation(g.shape[0])[:1500]] * 0.125).astype(np.float32)
+    v = np.concatenate([v, v[:40]])
+    f = np.array([[0, 1, 2], [3, 4, 5]], np.uint32)
+    q = np.concatenate([(rng.integers(-14, 15, (30000, 3)) * 0.0625), rng.uniform(-1, 1, (20000, 3)),
+                        v[rng.integers(0, v.shape[0], 3000)]]).astype(np.float32)
+    o = po.OracleSDF(v, f, False)
+    s = SDF(v, f, robust=False)
+    s.set_option("heavy_budget", budget)
+    s.set_option("profile", 1)
+    assert (s.nn(q) == o.nn(q)).all()
+    assert s.stats["last_heavy_points"] > (q.shape[0] // 2 if budget == 1 else 0)
+    assert same_float(s(q), o(q)).all()
+    # (b) torus, robust: sign by ray parity recomputed in the heavy kernel
+    v, f = meshes.torus(120, 120)
+    R = meshes.random_rotation(9)
+    o = po.OracleSDF(v, f, True, R)
+    s = SDF(v, f)
+    s.set_raycast_axes(R)
+    s.set_option("heavy_budget", budget)
+    p = np.concatenate([rng.uniform(-1, 1, (80000, 3)), meshes.grid_points(30),
+                        rng.normal(0, 1e-5, (3000, 3))]).astype(np.float32)  # + the symmetry centre
+    assert (s.nn(p) == o.nn(p)).all()
+    assert same_float(s(p), o(p)).all() and same_float(s(p, True), o(p, True)).all()
+    assert (s.contains(p) == o.contains(p)).all()
+    sn = SDF(v, f, robust=False)
+    sn.set_option("heavy_budget", budget)
+    on = po.OracleSDF(v, f, False)
+    assert same_float(sn(p), on(p)).all() and (sn.contains(p) == on.contains(p)).all()
+
+
+def test_sphere_centre_queries_take_the_heavy_path():
+    """icosphere: queries near the centre need (nearly) every vertex; with the automatic budget
+    their waves give up and the heavy kernel answers — same bits as the oracle."""
+    v, f = meshes.icosphere(6, radius=0.8)  # 40,962 v / 81,920 f
+    R = meshes.random_rotation(4)
+    o = po.OracleSDF(v, f, True, R)
+    s = SDF(v, f)
+    s.set_raycast_axes(R)
+    s.set_option("profile", 1)
+    rng = np.random.default_rng(8)
+    p = np.concatenate([rng.uniform(-1, 1, (150000, 3)), rng.uniform(-0.02, 0.02, (4000, 3)),
+                        np.zeros((64, 3))]).astype(np.float32)
+    n = s.nn(p)
+    assert s.stats["last_heavy_points"] >= 64
+    assert (n == o.nn(p)).all()
+    assert same_float(s(p), o(p)).all()

@@ -18,6 +18,8 @@ ap.add_argument("--nosort", type=int, default=0)
 ap.add_argument("--ray-mode", type=int, default=0)
 ap.add_argument("--noise", type=float, default=0.05)
 ap.add_argument("--group", type=int, default=0, help="packet_group option (0 = library default)")
+ap.add_argument("--heavy-budget", type=int, default=0)
+ap.add_argument("--rmin", type=float, default=0.0, help="drop points closer than this to the origin")
 a = ap.parse_args()
 if a.mesh.startswith("ico"):
     v, f = meshes.icosphere(int(a.mesh[3:]), radius=0.8, noise=a.noise, seed=3)
@@ -40,9 +42,13 @@ if a.grid:
 else:
     g = torch.Generator(device=dev).manual_seed(7)
     pts = torch.rand((a.n, 3), device=dev, generator=g).mul_(2).sub_(1)
+if a.rmin > 0:
+    pts = pts[pts.norm(dim=1) >= a.rmin].contiguous()
 n = pts.shape[0]
 if a.ray_mode:
     s.set_option("ray_mode", a.ray_mode)
+if a.heavy_budget:
+    s.set_option("heavy_budget", a.heavy_budget)
 if a.nosort:
     s.set_option("sort_queries", 0)
 print("stats", s.stats)
@@ -55,4 +61,4 @@ for name, fn in (("nn", s.nn), ("contains", s.contains), ("sdf", s.__call__)):
     s.set_option("profile", 2)
     for _ in range(a.reps):
         t0 = time.perf_counter(); fn(pts); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-    print(f"{name:9s} {best*1e3:9.2f} ms  {n/best/1e6:9.1f} Mevals/s  fallback {s.stats['last_fallback_points']}  kernel {s.stats['query_kernel_ms']/max(1,s.stats['query_kernel_launches']):.2f} ms", flush=True)
+    print(f"{name:9s} {best*1e3:9.2f} ms  {n/best/1e6:9.1f} Mevals/s  fallback {s.stats['last_fallback_points']} heavy {s.stats['last_heavy_points']}  kernel {s.stats['query_kernel_ms']/max(1,s.stats['query_kernel_launches']):.2f} ms", flush=True)
