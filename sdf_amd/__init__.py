@@ -4,5 +4,6 @@
 """
 from .pysdf import SDF, Renderer, SdfHipError, load_library, num_threads, pinned_empty  # noqa: F401
 from . import meshes  # noqa: F401
+from . import util  # noqa: F401  (pysdf.util, pybind.cpp:163-194)
 
-__all__ = ["SDF", "Renderer", "SdfHipError", "load_library", "num_threads", "pinned_empty", "meshes"]
+__all__ = ["SDF", "Renderer", "SdfHipError", "load_library", "num_threads", "pinned_empty", "meshes", "util"]

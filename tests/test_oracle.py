@@ -182,3 +182,34 @@ def test_generators_are_watertight_and_outward():
         assert all((y, x) in fwd for x, y in fwd) and len(fwd) == len(e)
     v, f = meshes.torus(424, 424)
     assert v.shape == (179776, 3) and f.shape == (359552, 3)
+
+
+def test_python_util_helpers_match_the_oracle_geometry():
+    """sdf_amd.util (= pysdf.util, pybind.cpp:163-194) against the oracle's restatement of
+    sdf.hpp:64-142 on random and degenerate inputs, bit for bit."""
+    import ctypes as C
+    from sdf_amd import util
+    L = po.lib()
+    fp = C.POINTER(C.c_float)
+    rng = np.random.default_rng(5)
+    for k in range(3000):
+        p, a, b, c = rng.uniform(-1, 1, (4, 3)).astype(np.float32)
+        if k % 7 == 0:
+            p = (a + b) / np.float32(2)          # on an edge
+        if k % 11 == 0:
+            c = a.copy()                         # degenerate triangle -> NaN
+        args = [x.ctypes.data_as(fp) for x in (p, a, b, c)]
+        got, want = np.float32(util.dist_point2tri(p, a, b, c)), np.float32(L.orc_dist_point2tri(*args))
+        assert got.view(np.uint32) == want.view(np.uint32) or (np.isnan(got) and np.isnan(want))
+        got, want = np.float32(util.dist_point2lineseg(p, a, b)), np.float32(L.orc_dist_point2lineseg(*args[:3]))
+        assert got.view(np.uint32) == want.view(np.uint32) or (np.isnan(got) and np.isnan(want))
+        bc = util.bary2d(p[:2], a[:2], b[:2], c[:2])
+        p2, a2, b2, c2 = [np.ascontiguousarray(x[:2]) for x in (p, a, b, c)]
+        inside = bool(L.orc_bary2d_inside(*[x.ctypes.data_as(fp) for x in (p2, a2, b2, c2)]))
+        assert inside == bool((bc >= 0).all())
+    # known answers
+    assert util.normal([0, 0, 0], [1, 0, 0], [0, 1, 0]).tolist() == [0, 0, 1]
+    assert util.dist_point2line([0, 1, 0], [0, 0, 0], [1, 0, 0]) == 1.0
+    assert util.dist_point2lineseg([3, 0, 0], [0, 0, 0], [1, 0, 0]) == 4.0
+    assert np.allclose(util.bary([0.25, 0.25, 5], [0, 0, 0], [1, 0, 0], [0, 1, 0]), [0.5, 0.25, 0.25])
+    assert util.dist_point2tri([0.25, 0.25, 2], [0, 0, 0], [1, 0, 0], [0, 1, 0]) == 4.0
