@@ -211,7 +211,8 @@ int sdfhip_host_alloc(size_t bytes, void** out);
 int sdfhip_host_free(void* p);
 
 /* Tuning knobs (no counterpart). key: "sort_queries" (0/1, default 1: Morton-sort query
- * chunks of >= sort_min points), "sort_min", "chunk" (points per internal chunk), "packet" (0: strict kernel only),
+ * chunks of >= sort_min points), "sort_min", "sort_min_contains" (the same threshold for robust contains(),
+ * default 12M: below it the ray walk runs on the caller's order), "chunk" (points per internal chunk), "packet" (0: strict kernel only),
  * "heavy_budget" (chunks of four vertices a wave of the packet pass may evaluate before its queries go
  * to the one-wave-per-query kernel; 0 = automatic: 1/8 of the tree), "fast_nn" (0/1, applies at the next update: the vertex tree is built on the GPU, no host kd-tree;
  * distances stay exact, an exact fp32 distance tie goes to the lowest (Morton code, index) vertex instead of the

@@ -61,6 +61,7 @@ def test_oracle_parity_medium_mesh_sorted_and_unsorted(sort):
     s = SDF(v, f, robust=True)
     s.set_raycast_axes(R)
     s.set_option("sort_queries", sort)
+    s.set_option("sort_min_contains", 0)  # robust contains through the packet kernel too (default: >= 12M points)
     assert (s.nn(pts) == o.nn(pts)).all()
     assert (s.contains(pts) == o.contains(pts)).all()
     assert same_float(s(pts), o(pts)).all()
@@ -145,6 +146,7 @@ def test_ray_grid_big_faces_and_coarsening():
         assert (s.raycast_detail(p) == o.raycast_detail(p)).all()
         assert (s.contains(p) == o.contains(p)).all()
         assert same_float(s(p), o(p)).all()
+        s.set_option("sort_min_contains", 0)
         for opt in (0, 1):  # strict and packet kernels share the grid
             s.set_option("sort_queries", opt)
             assert (s.contains(p[:20000]) == o.contains(p[:20000])).all()
