@@ -177,6 +177,11 @@ def main():
         if pm.get("traffic_bytes_per_launch") and n == 125_000_000 and not a.no_sort:
             roofline["traffic"] = pm["traffic_bytes_per_launch"]
             roofline["traffic_source"] = os.path.relpath(pj, ROOT)
+            # VALU utilisation of the same launch from the SQ counters of the same profile
+            # (issue slots of 1024 SIMDs at 2 cycles per wave64 instruction; active lanes)
+            for k in ("valu_issue_util", "valu_lane_util"):
+                if pm.get(k) is not None:
+                    roofline[k] = pm[k]
     except (IndexError, OSError, ValueError):
         pass
     extra = {}
