@@ -221,6 +221,17 @@ int rend_update(sdfhip_renderer* r) {
     float lo[2] = {0.f, 0.f}, hi[2] = {0.f, 0.f};
     if (b[0] != 0xFFFFFFFFu && b[2] != 0u) lo[0] = ord2f_host(b[0]), hi[0] = ord2f_host(b[2]);
     if (b[1] != 0xFFFFFFFFu && b[3] != 0u) lo[1] = ord2f_host(b[1]), hi[1] = ord2f_host(b[3]);
+    // A vertex close to the camera plane projects far away and would stretch the grid until the
+    // whole image is a single cell: when the boxes reach more than 4 images beyond the image, the
+    // grid covers the image and half of it on every side (cells clamp: the faces and the points
+    // outside share the border cells, the candidate sets stay supersets).
+    const float ext[2] = {(float)(r->width > 0 ? r->width : 1), (float)(r->height > 0 ? r->height : 1)};
+    for (int d = 0; d < 2; ++d)
+        if (hi[d] - lo[d] > 9.0f * ext[d]) {
+            lo[d] = lo[d] > -0.5f * ext[d] ? lo[d] : -0.5f * ext[d];
+            hi[d] = hi[d] < 1.5f * ext[d] ? hi[d] : 1.5f * ext[d];
+            if (!(hi[d] > lo[d])) lo[d] = -0.5f * ext[d], hi[d] = 1.5f * ext[d];
+        }
     r->grid.nbig = 0, r->grid.entries = 0;
     if (int rc = grid_build(r->grid, r->d_fbox, r->nf, lo, hi, 1, s)) return rc;
     HIPC(hipStreamSynchronize(s));

@@ -110,3 +110,25 @@ def test_edge_cases():
     # NaN / inf / huge query points terminate and hit nothing
     q = np.array([[np.nan, 1], [np.inf, 1], [1e30, -1e30], [1.5, 1.5]], np.float32)
     assert r.contains(q).tolist() == [False, False, False, True]
+
+
+def test_vertex_close_to_the_camera_plane_does_not_degrade_the_grid():
+    """one face reaching almost to z = 0 projects ~1e6 pixels wide: the grid keeps covering the
+    image (renderer.h, rend_update) and results stay exact"""
+    import time
+    v0, f = meshes.torus(200, 200)
+    v = v0.copy()
+    v[:, 2] += 2.0
+    v = np.concatenate([v, np.array([[0.3, 0.2, 1e-6], [0.31, 0.2, 2.0], [0.3, 0.21, 2.0]], np.float32)])
+    f = np.concatenate([f, np.array([[v.shape[0] - 3, v.shape[0] - 2, v.shape[0] - 1]], np.uint32)])
+    cam = (320, 240, 250.0, 250.0, 160.0, 120.0)
+    r = Renderer(v, f, *cam)
+    o = po.OracleRenderer(v, f, *cam)
+    assert same_float(r.render_depth(), o.render_depth()).all()
+    assert (r.render_nn(True) == o.render_nn(True)).all()
+    rng = np.random.default_rng(3)
+    p = np.concatenate([rng.uniform(-1, 2, (50000, 2)) * [320, 240], rng.uniform(-1e6, 1e6, (5000, 2))]).astype(np.float32)
+    assert same_float(r(p), o(p)).all() and (r.contains(p) == o.contains(p)).all()
+    t0 = time.perf_counter()
+    r.render_depth()
+    assert time.perf_counter() - t0 < 0.05  # one cell for the whole image would take far longer
