@@ -1,0 +1,372 @@
+// kernels_build.h — Morton codes, query bounds, the face LBVH (Karras topology, threaded layout, refit),
+// the GPU-built vertex tree of fast_nn and the column-grid fill.  Part of sdfhip.hip (one translation unit).
+#pragma once
+
+// =========================================================================================
+// Morton codes
+// =========================================================================================
+__device__ __forceinline__ uint32_t expand10(uint32_t v) {
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton30(float x, float y, float z, const float* lo, const float* inv) {
+    float fx = (x - lo[0]) * inv[0], fy = (y - lo[1]) * inv[1], fz = (z - lo[2]) * inv[2];
+    fx = fminf(fmaxf(fx, 0.f), 1023.f);
+    fy = fminf(fmaxf(fy, 0.f), 1023.f);
+    fz = fminf(fmaxf(fz, 0.f), 1023.f);
+    return (expand10((uint32_t)fx) << 2) | (expand10((uint32_t)fy) << 1) | expand10((uint32_t)fz);
+}
+
+struct Bounds {
+    float lo[3], inv[3];
+};
+
+__device__ __forceinline__ uint32_t expand16(uint32_t v) {  // 16 bits -> every other bit
+    v &= 0xFFFFu;
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+// Faces are ordered by the 2-D Morton code of their centroid in the (x', y') plane of the
+// ray-cast frame: the parity rays are columns along z', so faces that one column can meet —
+// whatever their z' — are neighbours in this order and share low subtrees.  (The x+ tie-break
+// ray walks the same tree less efficiently; it is cast only when z+ and z- disagree.)
+__global__ void k_face_morton(const float4* __restrict__ geo, uint32_t nf, Bounds B, RMat R,
+                              uint32_t* __restrict__ keys) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    const float4 g0 = geo[4 * (size_t)f], g1 = geo[4 * (size_t)f + 1], g2 = geo[4 * (size_t)f + 2];
+    const float cx = (g0.x + g0.w + g1.z) * (1.f / 3.f), cy = (g0.y + g1.x + g1.w) * (1.f / 3.f),
+                cz = (g0.z + g1.y + g2.x) * (1.f / 3.f);
+    const float rx = cx * R.m[0] + cy * R.m[3] + cz * R.m[6];
+    const float ry = cx * R.m[1] + cy * R.m[4] + cz * R.m[7];
+    float fx = (rx - B.lo[0]) * B.inv[0], fy = (ry - B.lo[1]) * B.inv[1];
+    fx = fminf(fmaxf(fx, 0.f), 65535.f);
+    fy = fminf(fmaxf(fy, 0.f), 65535.f);
+    keys[f] = (expand16((uint32_t)fx) << 1) | expand16((uint32_t)fy);
+}
+
+// query chunk bounds: block min/max -> atomics on an order-preserving uint encoding
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+static inline float ord2f_host(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float f;
+    std::memcpy(&f, &u, sizeof(f));
+    return f;
+}
+__global__ void k_bounds_init(uint32_t* b) {
+    if (threadIdx.x < 3) b[threadIdx.x] = 0xFFFFFFFFu;
+    else if (threadIdx.x < 6) b[threadIdx.x] = 0u;
+}
+// flat float view of the [n,3] points: thread-contiguous float4 loads (coordinate = index % 3);
+// base pointers from hipMalloc / torch are 16-byte aligned, the tail is read scalar
+__global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, int64_t n, uint32_t* b) {
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    const int64_t nf = 3 * n;
+    const bool aligned = (((uintptr_t)pts) & 15) == 0;
+    const int64_t ngroups = aligned ? nf / 12 : 0;  // 12 floats = 4 points = 3 float4
+    const float4* p4 = (const float4*)pts;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = p4[3 * g], c = p4[3 * g + 1], d = p4[3 * g + 2];
+        const float v[12] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const float x = v[k];
+            if (fabsf(x) <= FLT_MAX) {  // skips NaN and inf
+                lo[k % 3] = fminf(lo[k % 3], x);
+                hi[k % 3] = fmaxf(hi[k % 3], x);
+            }
+        }
+    }
+    for (int64_t i = 12 * ngroups + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = pts[i];
+        const int d = (int)(i % 3);
+        if (fabsf(x) <= FLT_MAX) {
+            if (d == 0) lo[0] = fminf(lo[0], x), hi[0] = fmaxf(hi[0], x);
+            else if (d == 1) lo[1] = fminf(lo[1], x), hi[1] = fmaxf(hi[1], x);
+            else lo[2] = fminf(lo[2], x), hi[2] = fmaxf(hi[2], x);
+        }
+    }
+    for (int d = 0; d < 3; ++d) {
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
+        }
+    }
+    // one set of atomics per block (they all hit the same six words)
+    __shared__ float red[4][6];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int d = 0; d < 3; ++d) red[w][d] = lo[d], red[w][3 + d] = hi[d];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        float v = red[0][d];
+        for (int k = 1; k < 4; ++k) v = d < 3 ? fminf(v, red[k][d]) : fmaxf(v, red[k][d]);
+        if (d < 3)
+            atomicMin(&b[d], f2ord(v));
+        else
+            atomicMax(&b[d], f2ord(v));
+    }
+}
+__global__ void k_query_morton(const float* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ b,
+                               uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float lo[3], inv[3];
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = ord2f(b[d]);
+        const float ext = ord2f(b[3 + d]) - lo[d];
+        inv[d] = ext > 0.f ? 1024.f / ext : 0.f;
+    }
+    // 8 bits per axis are plenty for wave coherence: 3 radix passes instead of 4
+    keys[i] = morton30(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], lo, inv) >> 6;
+}
+
+// =========================================================================================
+// LBVH topology (Karras 2012) over Morton-sorted faces, then a threaded pre-order layout.
+// Internal node i in [0, n-2], leaf p in [0, n-1] (sorted position).
+//   pre-order index of a node = 2 * lo + (#ancestors entered through their LEFT child)
+//   skip = index + 2 * (#leaves below) - 1
+// =========================================================================================
+struct LbvhTopo {
+    uint32_t* lo;       // [n-1] first leaf of internal node
+    uint32_t* hi;       // [n-1] last leaf
+    uint32_t* split;    // [n-1] gamma: left child covers [lo, gamma]
+    int32_t* parentI;   // [n-1] parent of internal node (-1 root)
+    int32_t* parentL;   // [n]   parent of leaf
+    uint32_t* posI;     // [n-1] pre-order index
+    uint32_t* posL;     // [n]
+    uint32_t* depthI;   // [n-1] #ancestors
+};
+
+__device__ __forceinline__ int lbvh_delta(const uint32_t* __restrict__ codes, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = ((unsigned long long)codes[i] << 32) | (uint32_t)i;
+    const unsigned long long b = ((unsigned long long)codes[j] << 32) | (uint32_t)j;
+    return __clzll((long long)(a ^ b));
+}
+
+__global__ void k_lbvh_karras(const uint32_t* __restrict__ codes, int n, LbvhTopo T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (lbvh_delta(codes, n, i, i + 1) - lbvh_delta(codes, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(codes, n, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(codes, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (lbvh_delta(codes, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = lbvh_delta(codes, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (lbvh_delta(codes, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    T.lo[i] = lo, T.hi[i] = hi, T.split[i] = gamma;
+    if (lo == gamma)
+        T.parentL[gamma] = i;
+    else
+        T.parentI[gamma] = i;
+    if (hi == gamma + 1)
+        T.parentL[gamma + 1] = i;
+    else
+        T.parentI[gamma + 1] = i;
+    if (i == 0) T.parentI[0] = -1;
+}
+
+// one thread per node (internal first, then leaves): walk to the root
+__global__ void k_lbvh_layout(int n, LbvhTopo T, const uint32_t* __restrict__ sorted_face,
+                              float4* __restrict__ rnodes, uint32_t* __restrict__ maxdepth) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n - 1) return;
+    const bool leaf = t >= n - 1;
+    const int id = leaf ? t - (n - 1) : t;
+    uint32_t mylo = leaf ? (uint32_t)id : T.lo[id];
+    const uint32_t lo0 = mylo, nleaves = leaf ? 1u : (T.hi[id] - T.lo[id] + 1u);
+    int par = leaf ? T.parentL[id] : T.parentI[id];
+    if (n == 1) par = -1;
+    uint32_t lefts = 0, depth = 0;
+    while (par >= 0) {
+        const uint32_t plo = T.lo[par];
+        lefts += (mylo == plo) ? 1u : 0u;
+        ++depth;
+        mylo = plo;
+        par = T.parentI[par];
+    }
+    const uint32_t pos = 2u * lo0 + lefts;
+    const uint32_t skip = pos + 2u * nleaves - 1u;
+    if (leaf) {
+        T.posL[id] = pos;
+        // box is filled by k_lbvh_leaf_boxes
+        rnodes[2 * (size_t)pos + 1] = make_float4(0.f, 0.f, __uint_as_float(skip),
+                                                  __uint_as_float(sorted_face[id]));
+    } else {
+        T.posI[id] = pos;
+        T.depthI[id] = depth;
+        rnodes[2 * (size_t)pos + 1] = make_float4(0.f, 0.f, __uint_as_float(skip), __uint_as_float(NOFACE));
+        atomicMax(maxdepth, depth);
+    }
+}
+
+__global__ void k_lbvh_leaf_boxes(int n, const uint32_t* __restrict__ posL,
+                                  const uint32_t* __restrict__ sorted_face,
+                                  const float* __restrict__ fbox, float4* __restrict__ rnodes) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t f = sorted_face[p], pos = posL[p];
+    const float* b = fbox + 6 * (size_t)f;
+    rnodes[2 * (size_t)pos] = make_float4(b[0], b[1], b[3], b[4]);
+    float4 w = rnodes[2 * (size_t)pos + 1];
+    w.x = b[2], w.y = b[5];
+    rnodes[2 * (size_t)pos + 1] = w;
+}
+
+// =========================================================================================
+// "fast_nn" mode: the vertex tree of the packet pass built entirely on the GPU (no host kd-tree).
+// Vertices are sorted by 30-bit Morton code; 16 consecutive ones form a packet group; an implicit
+// 4-ary tree of quad nodes is reduced bottom-up over the groups.  Distances and the minimum are
+// exact; what differs from the reference is the winner of an exact fp32 distance tie: the lowest
+// tree position (Morton order, equal codes by vertex index) instead of nanoflann's first-visited.
+// =========================================================================================
+__global__ void k_vtx_morton(const float* __restrict__ verts, uint32_t nv, Bounds B,
+                             uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    keys[i] = morton30(verts[3 * (size_t)i], verts[3 * (size_t)i + 1], verts[3 * (size_t)i + 2], B.lo, B.inv);
+}
+__global__ void k_fast_positions(const float* __restrict__ verts, const uint32_t* __restrict__ sorted_idx,
+                                 uint32_t nv, uint32_t nalloc, float4* __restrict__ pts4,
+                                 int32_t* __restrict__ vind) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nalloc) return;
+    if (i < nv) {
+        const uint32_t v = sorted_idx[i];
+        pts4[i] = make_float4(verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2], 3.0e38f);
+        vind[i] = (int32_t)v;
+    } else {
+        pts4[i] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f);
+        vind[i] = -1;
+    }
+}
+constexpr uint32_t FAST_GROUP = 16;  // vertices per packet group (4 chunks)
+__device__ __forceinline__ void quad_store(float4* q, int k, const float* lo, const float* hi, uint32_t ref,
+                                           float* flat) {
+    (void)q;
+    for (int d = 0; d < 3; ++d) flat[6 * k + d] = lo[d], flat[6 * k + 3 + d] = hi[d];
+    flat[24 + k] = __uint_as_float(ref);
+    flat[28 + k] = 0.f;
+}
+__global__ void k_fast_quads_leaf(const float4* __restrict__ pts4, uint32_t nv, uint32_t ngroups,
+                                  uint32_t nq, float4* __restrict__ out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float flat[32];
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t g = 4 * q + k;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t ref = KD_LEAF;  // unused slot: empty group (see kd_host.h quad_of)
+        if (g < ngroups) {
+            const uint32_t first = FAST_GROUP * g;
+            const uint32_t cnt = nv - first < FAST_GROUP ? nv - first : FAST_GROUP;
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const float4 p = pts4[first + j];
+                lo[0] = fminf(lo[0], p.x), lo[1] = fminf(lo[1], p.y), lo[2] = fminf(lo[2], p.z);
+                hi[0] = fmaxf(hi[0], p.x), hi[1] = fmaxf(hi[1], p.y), hi[2] = fmaxf(hi[2], p.z);
+            }
+            ref = KD_LEAF | ((first >> 2) << 4) | ((cnt + 3u) >> 2);
+        }
+        quad_store(nullptr, k, lo, hi, ref, flat);
+    }
+    for (int j = 0; j < 8; ++j)
+        out[8 * (size_t)q + j] = make_float4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
+}
+__global__ void k_fast_quads_inner(const float4* __restrict__ child, uint32_t nchild, uint32_t child_off,
+                                   uint32_t nq, float4* __restrict__ out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float flat[32];
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t c = 4 * q + k;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t ref = KD_LEAF;
+        if (c < nchild) {
+            const float* cf = (const float*)(child + 8 * (size_t)c);
+            for (int j = 0; j < 4; ++j)
+                for (int d = 0; d < 3; ++d) {
+                    lo[d] = fminf(lo[d], cf[6 * j + d]);
+                    hi[d] = fmaxf(hi[d], cf[6 * j + 3 + d]);
+                }
+            ref = child_off + c;
+        }
+        quad_store(nullptr, k, lo, hi, ref, flat);
+    }
+    for (int j = 0; j < 8; ++j)
+        out[8 * (size_t)q + j] = make_float4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
+}
+
+// column grid build: count (or fill) the cells each face's rotated AABB touches
+struct GridParams {
+    int g;
+    float o0, o1, inv0, inv1;
+};
+constexpr uint32_t GRID_BIG = 256;  // faces touching more cells go to the "big" list
+template <bool FILL>
+__global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridParams G,
+                             uint32_t* __restrict__ cells /* counts | cursors */,
+                             uint32_t* __restrict__ items, uint32_t* __restrict__ big,
+                             uint32_t* __restrict__ nbig, int skip_nan) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    const float* b = fbox + 6 * (size_t)f;
+    // Renderer: a face whose image-space box has a NaN is never inserted (renderer.cpp:52-56)
+    if (skip_nan && (b[0] != b[0] || b[1] != b[1] || b[3] != b[3] || b[4] != b[4])) return;
+    const int x0 = grid_cell(b[0], G.o0, G.inv0, G.g), x1 = grid_cell(b[3], G.o0, G.inv0, G.g);
+    const int y0 = grid_cell(b[1], G.o1, G.inv1, G.g), y1 = grid_cell(b[4], G.o1, G.inv1, G.g);
+    if (x1 < x0 || y1 < y0) return;  // NaN box: the face can never pass Overlap
+    const uint32_t nc = (uint32_t)(x1 - x0 + 1) * (uint32_t)(y1 - y0 + 1);
+    if (nc > GRID_BIG) {
+        if (!FILL) big[atomicAdd(nbig, 1u)] = f;
+        return;
+    }
+    for (int y = y0; y <= y1; ++y)
+        for (int x = x0; x <= x1; ++x) {
+            const uint32_t c = (uint32_t)y * (uint32_t)G.g + (uint32_t)x;
+            if (FILL)
+                items[atomicAdd(&cells[c], 1u)] = f;
+            else
+                atomicAdd(&cells[c], 1u);
+        }
+}
+
+// one launch per depth, deepest first: children are complete (previous launch / leaves)
+__global__ void k_lbvh_fit(int n, LbvhTopo T, uint32_t depth, float4* __restrict__ rnodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || T.depthI[i] != depth) return;
+    const uint32_t pos = T.posI[i];
+    const uint32_t c1 = pos + 1, c2 = pos + 2u * (T.split[i] - T.lo[i] + 1u);
+    const float4 a1 = rnodes[2 * (size_t)c1], b1 = rnodes[2 * (size_t)c1 + 1];
+    const float4 a2 = rnodes[2 * (size_t)c2], b2 = rnodes[2 * (size_t)c2 + 1];
+    rnodes[2 * (size_t)pos] =
+        make_float4(fminf(a1.x, a2.x), fminf(a1.y, a2.y), fmaxf(a1.z, a2.z), fmaxf(a1.w, a2.w));
+    float4 w = rnodes[2 * (size_t)pos + 1];
+    w.x = fminf(b1.x, b2.x), w.y = fmaxf(b1.y, b2.y);
+    rnodes[2 * (size_t)pos + 1] = w;
+}

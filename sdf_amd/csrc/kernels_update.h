@@ -1,0 +1,101 @@
+// kernels_update.h — sample_surface and the per-face precompute of update().  Part of sdfhip.hip.
+#pragma once
+
+// =========================================================================================
+// sample_surface (sdf.cpp:176-234): face by inverse-CDF over the running sum of face areas,
+// then a uniform point of the parallelogram (a, ab, ac) reflected over bc.  The reference draws
+// from a time-seeded mt19937 (util.cpp:32-40); here sample j takes its three uniforms from
+// Philox4x32-10(key = seed, counter = j), so a call is reproducible and order independent.
+// =========================================================================================
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0, c1 = l1, c2 = n2, c3 = l0;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t x) {  // [0, 1 - eps], sdf.cpp:182-183
+    return ((float)(x >> 8) * 5.9604644775390625e-8f) * (1.0f - FLT_EPSILON);
+}
+__global__ void k_sample_surface(const float4* __restrict__ geo, const float* __restrict__ cum,
+                                 uint32_t nf, float total_area, uint64_t seed, int64_t n,
+                                 float* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t x[4];
+    philox4x32_10((uint32_t)j, (uint32_t)((uint64_t)j >> 32), 0u, 0u, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), x);
+    const float r = u01(x[0]) * total_area;
+    // std::lower_bound: first index whose running sum is not less than r (sdf.cpp:205-209)
+    uint32_t lo = 0, cnt = nf;
+    while (cnt > 0) {
+        const uint32_t half = cnt >> 1;
+        if (cum[lo + half] < r)
+            lo += half + 1, cnt -= half + 1;
+        else
+            cnt = half;
+    }
+    const uint32_t i = lo < nf - 1 ? lo : nf - 1;
+    const float4 g0 = geo[4 * (size_t)i], g1 = geo[4 * (size_t)i + 1], g2 = geo[4 * (size_t)i + 2];
+    const V3 a = {g0.x, g0.y, g0.z}, b = {g0.w, g1.x, g1.y}, c = {g1.z, g1.w, g2.x};
+    const V3 nrm = {g2.y, g2.z, g2.w};
+    const V3 ab = sdfk::sub(b, a), ac = sdfk::sub(c, a), bc = sdfk::sub(c, b);
+    V3 perp = sdfk::cross(bc, nrm);
+    const float pn = __builtin_sqrtf(sdfk::sqnorm(perp));  // normalized(): v / norm()
+    if (pn > 0.f) perp = {perp.x / pn, perp.y / pn, perp.z / pn};
+    const bool a_dir = sdfk::dot(ab, perp) < 0.0f;
+    const float u = u01(x[1]), w = u01(x[2]);
+    V3 p = {(a.x + u * ab.x) + w * ac.x, (a.y + u * ab.y) + w * ac.y, (a.z + u * ab.z) + w * ac.z};
+    const float bp = sdfk::dot(sdfk::sub(p, b), perp);
+    if ((bp >= 0.0f) != a_dir)
+        p = {p.x - (bp * perp.x) * 2.f, p.y - (bp * perp.y) * 2.f, p.z - (bp * perp.z) * 2.f};
+    out[3 * j] = p.x, out[3 * j + 1] = p.y, out[3 * j + 2] = p.z;
+}
+
+
+// =========================================================================================
+// update(): per-face precompute (sdf.cpp:50-70)
+// =========================================================================================
+struct RMat {
+    float m[9];
+};
+
+__global__ void k_face_precompute(const float* __restrict__ verts, const uint32_t* __restrict__ faces,
+                                  uint32_t nf, RMat R, int robust, float4* __restrict__ geo,
+                                  float4* __restrict__ rface, float* __restrict__ fbox,
+                                  float* __restrict__ normals, float* __restrict__ areas) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    const uint32_t ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
+    const V3 a = {verts[3 * (size_t)ia], verts[3 * (size_t)ia + 1], verts[3 * (size_t)ia + 2]};
+    const V3 b = {verts[3 * (size_t)ib], verts[3 * (size_t)ib + 1], verts[3 * (size_t)ib + 2]};
+    const V3 c = {verts[3 * (size_t)ic], verts[3 * (size_t)ic + 1], verts[3 * (size_t)ic + 2]};
+    V3 n = sdfk::cross(sdfk::sub(b, a), sdfk::sub(c, a));  // sdf.hpp:75-81
+    const float area = __builtin_sqrtf(sdfk::sqnorm(n));     // sdf.cpp:68
+    n = {n.x / area, n.y / area, n.z / area};                 // sdf.cpp:69
+    areas[f] = area;
+    normals[3 * f] = n.x, normals[3 * f + 1] = n.y, normals[3 * f + 2] = n.z;
+    geo[4 * (size_t)f] = make_float4(a.x, a.y, a.z, b.x);
+    geo[4 * (size_t)f + 1] = make_float4(b.y, b.z, c.x, c.y);
+    geo[4 * (size_t)f + 2] = make_float4(c.z, n.x, n.y, n.z);
+    geo[4 * (size_t)f + 3] = make_float4(area, 0.f, 0.f, 0.f);
+    if (robust) {
+        const V3 ra = sdfk::mulR(a, R.m), rb = sdfk::mulR(b, R.m), rc = sdfk::mulR(c, R.m);
+        const V3 rn = sdfk::mulR(n, R.m);  // sdf.cpp:299-300
+        V3 mn = ra, mx = ra;               // sdf.cpp:54-63
+        mn = {sdfk::stdmin(mn.x, rb.x), sdfk::stdmin(mn.y, rb.y), sdfk::stdmin(mn.z, rb.z)};
+        mn = {sdfk::stdmin(mn.x, rc.x), sdfk::stdmin(mn.y, rc.y), sdfk::stdmin(mn.z, rc.z)};
+        mx = {sdfk::stdmax(mx.x, rb.x), sdfk::stdmax(mx.y, rb.y), sdfk::stdmax(mx.z, rb.z)};
+        mx = {sdfk::stdmax(mx.x, rc.x), sdfk::stdmax(mx.y, rc.y), sdfk::stdmax(mx.z, rc.z)};
+        rface[3 * (size_t)f] = make_float4(ra.x, ra.y, ra.z, rb.x);
+        rface[3 * (size_t)f + 1] = make_float4(rb.y, rb.z, rc.x, rc.y);
+        rface[3 * (size_t)f + 2] = make_float4(rc.z, rn.x, rn.y, rn.z);
+        fbox[6 * (size_t)f] = mn.x, fbox[6 * (size_t)f + 1] = mn.y, fbox[6 * (size_t)f + 2] = mn.z;
+        fbox[6 * (size_t)f + 3] = mx.x, fbox[6 * (size_t)f + 4] = mx.y, fbox[6 * (size_t)f + 5] = mx.z;
+    }
+}

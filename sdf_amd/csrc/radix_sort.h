@@ -1,0 +1,223 @@
+// radix_sort.h — hand-written LDS radix sort of (u32 key, u32 value) pairs + the exclusive scan it uses.
+// Part of sdfhip.hip (one translation unit).
+#pragma once
+
+// =========================================================================================
+// LDS radix sort of (u32 key, u32 value) pairs, 8 bits per pass, stable.
+//   k_rs_hist   : per-tile digit histogram (LDS atomics) -> hist[digit][tile]
+//   scan        : exclusive scan of hist (digit-major), hierarchical
+//   k_rs_scatter: per 64-key wave chunk, ballot "match" masks give each key its stable rank
+//                 among equal digits; chunk bases are scanned in LDS per digit
+// =========================================================================================
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 12;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 3072
+constexpr int RS_CHUNKS = RS_TILE / 64;         // 48
+
+// element (k, t) of a tile = index base + k * 256 + t, so a wave reads 64 consecutive keys
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t* __restrict__ keys, uint32_t n,
+                                                        int shift, uint32_t* __restrict__ hist,
+                                                        uint32_t ntiles) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// block-level exclusive scan of 2048 entries per block; block totals to sums[]
+__global__ __launch_bounds__(256) void k_scan_block(uint32_t* __restrict__ data, uint32_t n,
+                                                    uint32_t* __restrict__ sums) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t base = blockIdx.x * 2048u + threadIdx.x * 8u;
+    uint32_t v[8], t = 0;
+    for (int k = 0; k < 8; ++k) {
+        v[k] = (base + k < n) ? data[base + k] : 0u;
+        t += v[k];
+    }
+    // inclusive scan of t across the block
+    uint32_t x = t;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    uint32_t run = woff + x - t;
+    for (int k = 0; k < 8; ++k) {
+        if (base + k < n) data[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 255 && sums) sums[blockIdx.x] = woff + x;
+}
+__global__ void k_scan_add(uint32_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ sums) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) data[i] += sums[i / 2048u];
+}
+
+// in-place exclusive scan of n u32 (n <= 2048^3); s1/s2 hold ceil(n/2048) and ceil(n/2048^2) sums
+static int exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* s1, uint32_t* s2, hipStream_t s) {
+    if (n == 0) return 0;
+    const uint32_t n1 = (n + 2047) / 2048, n2 = (n1 + 2047) / 2048;
+    k_scan_block<<<n1, 256, 0, s>>>(data, n, s1);
+    if (n1 > 1) {
+        k_scan_block<<<n2, 256, 0, s>>>(s1, n1, s2);
+        if (n2 > 1) {
+            k_scan_block<<<1, 256, 0, s>>>(s2, n2, nullptr);
+            k_scan_add<<<(n1 + 255) / 256, 256, 0, s>>>(s1, n1, s2);
+        }
+        k_scan_add<<<(n + 255) / 256, 256, 0, s>>>(data, n, s1);
+    }
+    return 0;
+}
+
+// Stable scatter of one tile.  Ranks come from per-64-key-chunk ballot "match" masks; the tile
+// is first permuted into digit order inside LDS so that consecutive lanes then write
+// consecutive global addresses (runs of tile/256 elements per digit instead of single keys).
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+    const uint32_t* __restrict__ hist, uint32_t ntiles, int vals_iota) {
+    __shared__ uint16_t cnt[RS_CHUNKS * 256];  // per (chunk, digit) counts -> offsets   24 KB
+    __shared__ uint32_t skey[RS_TILE];         // tile in digit order                   12 KB
+    __shared__ uint32_t sval[RS_TILE];         //                                       12 KB
+    __shared__ uint32_t bstart[256];           // first local slot of each digit
+    __shared__ uint32_t gbase[256];            // global base of each digit for this tile
+    __shared__ uint32_t wsum[4];
+    for (int k = threadIdx.x; k < RS_CHUNKS * 256; k += RS_THREADS) cnt[k] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * RS_TILE;
+    uint32_t key[RS_ITEMS], val[RS_ITEMS];
+    uint16_t rank[RS_ITEMS];
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int chunk = k * 4 + w;  // ascending key index
+        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+        const bool valid = i < n;
+        key[k] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        val[k] = valid ? (vals_iota ? i : vals_in[i]) : 0u;
+        const uint32_t dg = (key[k] >> shift) & 255u;
+        unsigned long long m = __ballot(valid);
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bl = __ballot((dg >> b) & 1u);
+            m &= ((dg >> b) & 1u) ? bl : ~bl;
+        }
+        rank[k] = (uint16_t)__popcll(m & lt);
+        if (valid && rank[k] == 0) cnt[chunk * 256 + dg] = (uint16_t)__popcll(m);
+    }
+    __syncthreads();
+    {   // thread = digit: offsets of its chunks, then a block scan of the digit totals
+        const uint32_t dg = threadIdx.x;
+        uint32_t run = 0;
+        for (int c = 0; c < RS_CHUNKS; ++c) {
+            const uint32_t t = cnt[c * 256 + dg];
+            cnt[c * 256 + dg] = (uint16_t)run;
+            run += t;
+        }
+        uint32_t x = run;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        bstart[dg] = woff + x - run;
+        gbase[dg] = hist[dg * ntiles + blockIdx.x];
+    }
+    __syncthreads();
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int chunk = k * 4 + w;
+        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+        if (i < n) {
+            const uint32_t dg = (key[k] >> shift) & 255u;
+            const uint32_t slot = bstart[dg] + cnt[chunk * 256 + dg] + rank[k];
+            skey[slot] = key[k];
+            sval[slot] = val[k];
+        }
+    }
+    __syncthreads();
+    const uint32_t tile_n = (n - base) < (uint32_t)RS_TILE ? (n - base) : (uint32_t)RS_TILE;
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const uint32_t slot = k * RS_THREADS + threadIdx.x;
+        if (slot < tile_n) {
+            const uint32_t kk = skey[slot];
+            const uint32_t dg = (kk >> shift) & 255u;
+            const uint32_t dst = gbase[dg] + (slot - bstart[dg]);
+            keys_out[dst] = kk;
+            vals_out[dst] = sval[slot];
+        }
+    }
+}
+
+struct RadixSorter {
+    uint32_t* keys_alt = nullptr;
+    uint32_t* vals_alt = nullptr;
+    uint32_t* hist = nullptr;
+    uint32_t* sums1 = nullptr;
+    uint32_t* sums2 = nullptr;
+    uint32_t cap = 0;
+
+    int reserve(uint32_t n) {
+        if (n <= cap) return 0;
+        release();
+        const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+        const uint32_t nh = 256u * ntiles;
+        const uint32_t n1 = (nh + 2047) / 2048, n2 = (n1 + 2047) / 2048;
+        HIPC(hipMalloc(&keys_alt, sizeof(uint32_t) * (size_t)n));
+        HIPC(hipMalloc(&vals_alt, sizeof(uint32_t) * (size_t)n));
+        HIPC(hipMalloc(&hist, sizeof(uint32_t) * (size_t)nh));
+        HIPC(hipMalloc(&sums1, sizeof(uint32_t) * (size_t)(n1 + 1)));
+        HIPC(hipMalloc(&sums2, sizeof(uint32_t) * (size_t)(n2 + 1)));
+        cap = n;
+        return 0;
+    }
+    void release() {
+        void* ps[] = {keys_alt, vals_alt, hist, sums1, sums2};
+        for (void* p : ps)
+            if (p) (void)hipFree(p);
+        keys_alt = vals_alt = hist = sums1 = sums2 = nullptr;
+        cap = 0;
+    }
+    // sorts (keys, vals) ascending by the low `bits` bits of keys (8 bits per pass).  The result
+    // is in *keys_out / *vals_out: the caller's buffers after an even number of passes, the
+    // sorter's alternates after an odd number.  iota = 1: input values are taken as 0..n-1.
+    int sort(uint32_t* keys, uint32_t* vals, uint32_t n, int bits, int iota, hipStream_t s,
+             uint32_t** keys_out, uint32_t** vals_out) {
+        if (keys_out) *keys_out = keys;
+        if (vals_out) *vals_out = vals;
+        if (n == 0) return 0;
+        if (int rc = reserve(n)) return rc;
+        const int passes = (bits + 7) / 8;
+        const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+        const uint32_t nh = 256u * ntiles;
+        const uint32_t n1 = (nh + 2047) / 2048, n2 = (n1 + 2047) / 2048;
+        if (n2 > 2048) return fail(SDFHIP_E_INVALID, "radix sort: too many keys (%u)", n);
+        uint32_t *ki = keys, *vi = vals, *ko = keys_alt, *vo = vals_alt;
+        for (int p = 0; p < passes; ++p) {
+            const int shift = 8 * p;
+            k_rs_hist<<<ntiles, RS_THREADS, 0, s>>>(ki, n, shift, hist, ntiles);
+            exclusive_scan_u32(hist, nh, sums1, sums2, s);
+            k_rs_scatter<<<ntiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, hist, ntiles,
+                                                       (p == 0 && iota) ? 1 : 0);
+            uint32_t* t = ki;
+            ki = ko, ko = t;
+            t = vi;
+            vi = vo, vo = t;
+        }
+        if (keys_out) *keys_out = ki;
+        if (vals_out) *vals_out = vi;
+        HIPC(hipGetLastError());
+        return 0;
+    }
+};
