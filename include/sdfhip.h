@@ -213,7 +213,8 @@ int sdfhip_host_free(void* p);
 /* Tuning knobs (no counterpart). key: "sort_queries" (0/1, default 1: Morton-sort query
  * chunks of >= sort_min points), "sort_min", "sort_min_contains" (the same threshold for robust contains(),
  * default 12M: below it the ray walk runs on the caller's order), "chunk" (points per internal chunk), "packet" (0: strict kernel only),
- * "heavy_budget" (chunks of four vertices a wave of the packet pass may evaluate before its queries go
+ * "scan_max" (batches with points x padded vertices up to this value are answered by the exact one-wave-per-query
+ * scan instead of a tree walk; -1 = automatic (the default: ~5e8 x (vertices / 4000)^0.57), 0 = never), "heavy_budget" (chunks of four vertices a wave of the packet pass may evaluate before its queries go
  * to the one-wave-per-query kernel; 0 = automatic: 1/8 of the tree), "fast_nn" (0/1, applies at the next update: the vertex tree is built on the GPU, no host kd-tree;
  * distances stay exact, an exact fp32 distance tie goes to the lowest (Morton code, index) vertex instead of the
  * reference's first-visited one), "packet_group" (vertices per leaf group of the packet pass, 10..60, applies at the next update), "host_chunk" (points per

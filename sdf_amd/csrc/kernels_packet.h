@@ -424,52 +424,58 @@ __global__ void k_fb_compact(const unsigned long long* __restrict__ amb_mask,
     if (i == n - 1) *total_out = base + (uint32_t)__popcll(m);
 }
 
-// The queries of the waves that gave up in the packet pass: ONE WAVE PER QUERY, the 64 lanes
-// stride over all (padded) tree positions — no pruning, no dependent loads, V / 64 steps.  The
-// (four queries per pass share each vertex load).  The same three things come out as from the packet pass: the exact fp32 minimum b, the second
-// smallest distance s as a multiset (always exact here), and h = among the vertices at distance
-// exactly b the one nanoflann's DFS meets first (folded pairwise with kd_dfs_first, a total order
-// for a fixed query; fast_nn: the lowest position).  Then the packet kernel's own decision:
-// window test, path check, else defer to the strict kernel's list.
-constexpr int HEAVY_Q = 4;  // queries per wave pass: one vertex load serves four distance evaluations
-template <int KIND, bool ROBUST>
-__global__ __launch_bounds__(256) void k_query_heavy(MeshDev M, const float* __restrict__ pts,
-                                                     const uint32_t* __restrict__ heavy_list,
-                                                     const uint32_t* __restrict__ heavy_cnt, int trunc_aabb,
-                                                     void* __restrict__ out, uint32_t* __restrict__ fb_list,
-                                                     uint32_t* __restrict__ fb_cnt) {
-    const uint32_t cnt = *heavy_cnt;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t q0 = HEAVY_Q * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6); q0 < cnt; q0 += HEAVY_Q * nw) {
+// The exact scan.  Answers (a) the queries of the waves that gave up in the packet pass (heavy
+// list) and (b) whole small batches ("scan mode", heavy_cnt == nullptr): a BLOCK of WAVES waves
+// takes HEAVY_Q queries at a time and its threads stride over all (padded) tree positions — no
+// pruning, no dependent loads.  One vertex load serves HEAVY_Q distance evaluations; loads go out
+// four at a time; the body is branch-free (the loop is latency bound otherwise).  The same three
+// things come out as from the packet pass: the exact fp32 minimum b, the second smallest distance
+// s as a multiset (always exact here), and h = among the vertices at distance exactly b the one
+// nanoflann's DFS meets first (fast_nn: the lowest position).  Then the packet kernel's own
+// decision: window test, path check, else defer to the strict kernel's list.
+// pos_out != nullptr (scan mode, kinds with a tail): the tree position (-1 none, -2 deferred) is
+// stored per query and k_scan_finish does ray parity + face distances one lane per query.
+constexpr int HEAVY_Q = 4;
+template <int KIND, bool ROBUST, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_query_heavy(MeshDev M, const float* __restrict__ pts,
+                                                            const uint32_t* __restrict__ heavy_list,
+                                                            const uint32_t* __restrict__ heavy_cnt,
+                                                            int trunc_aabb, void* __restrict__ out,
+                                                            uint32_t* __restrict__ fb_list,
+                                                            uint32_t* __restrict__ fb_cnt, uint32_t cnt_all,
+                                                            int32_t* __restrict__ pos_out) {
+    __shared__ uint32_t sb[WAVES][HEAVY_Q], ss[WAVES][HEAVY_Q], sh[WAVES][HEAVY_Q];
+    const uint32_t cnt = heavy_cnt ? *heavy_cnt : cnt_all;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr uint32_t STEP = 64u * WAVES;  // positions per block per sub-step
+    for (uint32_t q0 = HEAVY_Q * blockIdx.x; q0 < cnt; q0 += HEAVY_Q * gridDim.x) {  // block-uniform
         uint32_t src[HEAVY_Q], b[HEAVY_Q], s2[HEAVY_Q], h[HEAVY_Q];
         V3 p[HEAVY_Q];
 #pragma unroll
         for (int j = 0; j < HEAVY_Q; ++j) {
             const uint32_t q = q0 + j < cnt ? q0 + j : cnt - 1;  // the tail repeats the last query
-            src[j] = heavy_list[q];
+            src[j] = heavy_cnt ? heavy_list[q] : q;
             p[j] = {pts[3 * (size_t)src[j]], pts[3 * (size_t)src[j] + 1], pts[3 * (size_t)src[j] + 2]};
             b[j] = 0x7F7FFFFFu, s2[j] = 0x7F7FFFFFu, h[j] = H_NONE;
         }
-        // four positions per step, their loads issued together (the loop is latency bound
-        // otherwise).  Uniform trip count and no branch in the body: a position past the end reads
-        // the last slot and gets the distance 0xFFFFFFFF, which changes nothing.
-        for (uint32_t k0 = 0; k0 < M.kd_npos; k0 += 256u) {
+        // Uniform trip count, no branch in the body: a position past the end reads the last slot
+        // and gets the distance 0xFFFFFFFF, which changes nothing.
+        for (uint32_t k0 = 0; k0 < M.kd_npos; k0 += 4u * STEP) {
             float4 P[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint32_t k = k0 + 64u * u + lane;
+                const uint32_t k = k0 + STEP * u + threadIdx.x;
                 P[u] = M.kd_pts4[k < M.kd_npos ? k : M.kd_npos - 1];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint32_t k = k0 + 64u * u + lane;
+                const uint32_t k = k0 + STEP * u + threadIdx.x;
 #pragma unroll
                 for (int j = 0; j < HEAVY_Q; ++j) {
                     const float dx = p[j].x - P[u].x, dy = p[j].y - P[u].y, dz = p[j].z - P[u].z;
                     uint32_t du = __float_as_uint((dx * dx + dy * dy) + dz * dz);
                     du = k < M.kd_npos ? du : 0xFFFFFFFFu;
-                    // branch-free: on du == b the earlier (lower) position stays, s2 = b flags the tie
+                    // on du == b the earlier (lower) position stays and s2 = b flags the tie
                     const bool lt = du < b[j];
                     s2[j] = lt ? b[j] : min(s2[j], du);
                     h[j] = lt ? k : h[j];
@@ -477,6 +483,7 @@ __global__ __launch_bounds__(256) void k_query_heavy(MeshDev M, const float* __r
                 }
             }
         }
+        // wave reduction, then the block's waves through LDS; every thread ends with the merged triple
 #pragma unroll
         for (int j = 0; j < HEAVY_Q; ++j) {
             for (int o = 32; o >= 1; o >>= 1) {
@@ -486,46 +493,73 @@ __global__ __launch_bounds__(256) void k_query_heavy(MeshDev M, const float* __r
                 b[j] = min(b[j], ob);
                 h[j] = nh;
             }
-            // Exact tie (wave-uniform after the reduction): h is the lowest tied position, which is
-            // the fast_nn rule; nanoflann's rule wants the tied vertex its DFS meets first: second
-            // scan over the vertices at distance exactly b, folded with kd_dfs_first (a total
-            // order for a fixed query).  Kept out of the main loop: one tree walk per tied vertex.
-            if (s2[j] == b[j] && h[j] != H_NONE && !M.fast) {
-                uint32_t hh = H_NONE;
-                for (uint32_t k0 = 0; k0 < M.kd_npos; k0 += 256u) {
-                    uint32_t du[4];
+            if (lane == 0) sb[wave][j] = b[j], ss[wave][j] = s2[j], sh[wave][j] = h[j];
+        }
+        __syncthreads();
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t k = k0 + 64u * u + lane;
-                        const float4 P = M.kd_pts4[k < M.kd_npos ? k : M.kd_npos - 1];
-                        const float dx = p[j].x - P.x, dy = p[j].y - P.y, dz = p[j].z - P.z;
-                        du[u] = k < M.kd_npos ? __float_as_uint((dx * dx + dy * dy) + dz * dz) : 0xFFFFFFFFu;
-                    }
-                    if (__ballot(du[0] == b[j] || du[1] == b[j] || du[2] == b[j] || du[3] == b[j]) == 0ull) continue;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t k = k0 + 64u * u + lane;
-                        if (du[u] == b[j])
-                            hh = hh == H_NONE ? k : (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)hh, (int)k);
-                    }
-                }
-                for (int o = 32; o >= 1; o >>= 1) {
-                    const uint32_t oh = __shfl_xor(hh, o);
-                    if (hh == H_NONE)
-                        hh = oh;
-                    else if (oh != H_NONE)
-                        hh = (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)hh, (int)oh);
-                }
-                h[j] = hh;
+        for (int j = 0; j < HEAVY_Q; ++j) {
+            b[j] = sb[0][j], s2[j] = ss[0][j], h[j] = sh[0][j];
+            for (int w = 1; w < WAVES; ++w) {
+                const uint32_t ob = sb[w][j], os = ss[w][j], oh = sh[w][j];
+                const uint32_t nh = ob < b[j] ? oh : (b[j] < ob ? h[j] : min(h[j], oh));
+                s2[j] = min(min(s2[j], os), max(b[j], ob));
+                b[j] = min(b[j], ob);
+                h[j] = nh;
             }
         }
-        // lane j finishes query j
-        if (lane >= (uint32_t)HEAVY_Q || q0 + lane >= cnt) continue;
+        __syncthreads();  // LDS is reused below
+        // Exact tie (block-uniform): h is the lowest tied position, which is the fast_nn rule;
+        // nanoflann's rule wants the tied vertex its DFS meets first: second scan over the
+        // vertices at distance exactly b, folded with kd_dfs_first (a total order for a fixed
+        // query).  Kept out of the main loop: one tree walk per tied vertex.
+#pragma unroll
+        for (int j = 0; j < HEAVY_Q; ++j) {
+            if (!(s2[j] == b[j] && h[j] != H_NONE && !M.fast)) continue;
+            uint32_t hh = H_NONE;
+            for (uint32_t k0 = 0; k0 < M.kd_npos; k0 += 4u * STEP) {
+                uint32_t du[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t k = k0 + STEP * u + threadIdx.x;
+                    const float4 P = M.kd_pts4[k < M.kd_npos ? k : M.kd_npos - 1];
+                    const float dx = p[j].x - P.x, dy = p[j].y - P.y, dz = p[j].z - P.z;
+                    du[u] = k < M.kd_npos ? __float_as_uint((dx * dx + dy * dy) + dz * dz) : 0xFFFFFFFFu;
+                }
+                if (__ballot(du[0] == b[j] || du[1] == b[j] || du[2] == b[j] || du[3] == b[j]) == 0ull) continue;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t k = k0 + STEP * u + threadIdx.x;
+                    if (du[u] == b[j])
+                        hh = hh == H_NONE ? k : (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)hh, (int)k);
+                }
+            }
+            for (int o = 32; o >= 1; o >>= 1) {
+                const uint32_t oh = __shfl_xor(hh, o);
+                if (hh == H_NONE)
+                    hh = oh;
+                else if (oh != H_NONE)
+                    hh = (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)hh, (int)oh);
+            }
+            if (lane == 0) sh[wave][j] = hh;
+            __syncthreads();
+            hh = sh[0][j];
+            for (int w = 1; w < WAVES; ++w) {
+                const uint32_t oh = sh[w][j];
+                if (hh == H_NONE)
+                    hh = oh;
+                else if (oh != H_NONE)
+                    hh = (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)hh, (int)oh);
+            }
+            h[j] = hh;
+            __syncthreads();
+        }
+        // thread j of the block finishes query j
+        if (threadIdx.x >= (uint32_t)HEAVY_Q || q0 + threadIdx.x >= cnt) continue;
         uint32_t mb = b[0], ms = s2[0], mh = h[0], msrc = src[0];
         V3 mp = p[0];
 #pragma unroll
         for (int j = 1; j < HEAVY_Q; ++j)
-            if (lane == (uint32_t)j) mb = b[j], ms = s2[j], mh = h[j], msrc = src[j], mp = p[j];
+            if (threadIdx.x == (uint32_t)j) mb = b[j], ms = s2[j], mh = h[j], msrc = src[j], mp = p[j];
         const int pos = mh == H_NONE ? -1 : (int)mh;
         const float bf = __uint_as_float(mb), sf = __uint_as_float(ms);
         bool amb = false;
@@ -536,8 +570,10 @@ __global__ __launch_bounds__(256) void k_query_heavy(MeshDev M, const float* __r
             }
             if (pos < 0) amb = true;
         }
-        if (amb) {
-            fb_list[atomicAdd(fb_cnt, 1u)] = msrc;
+        if (amb) fb_list[atomicAdd(fb_cnt, 1u)] = msrc;
+        if (pos_out) {
+            pos_out[msrc] = amb ? -2 : pos;
+        } else if (amb) {
         } else if (KIND == Q_NN) {
             ((int32_t*)out)[msrc] = pos >= 0 ? M.kd_vind[pos] : -1;
         } else {
@@ -551,4 +587,28 @@ __global__ __launch_bounds__(256) void k_query_heavy(MeshDev M, const float* __r
                 ((float*)out)[msrc] = v;
         }
     }
+}
+
+// scan mode, kinds with a tail: ray parity + incident-face distances, one lane per query
+template <int KIND, bool ROBUST>
+__global__ __launch_bounds__(256) void k_scan_finish(MeshDev M, const float* __restrict__ pts,
+                                                     const int32_t* __restrict__ pos_in, uint32_t n,
+                                                     int trunc_aabb, void* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int pos = pos_in[i];
+    if (pos == -2) return;  // deferred: the strict kernel answers it
+    const V3 p = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+    if (KIND == Q_NN) {
+        ((int32_t*)out)[i] = pos >= 0 ? M.kd_vind[pos] : -1;
+        return;
+    }
+    float sign = 0.f;
+    if (ROBUST) sign = raycast(M, p, nullptr);
+    const bool trunc = (KIND == Q_CONTAINS) ? true : (trunc_aabb != 0);
+    const float v = calc_tail<ROBUST>(M, p, trunc, sign, pos);
+    if (KIND == Q_CONTAINS)
+        ((uint8_t*)out)[i] = v >= 0;
+    else
+        ((float*)out)[i] = v;
 }

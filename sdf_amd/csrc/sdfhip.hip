@@ -145,6 +145,7 @@ struct sdfhip_ctx {
     uint32_t last_fb = 0;  // length of the last deferred list (read back only while profiling)
     uint32_t last_heavy = 0;  // queries of the last call's heavy waves (same)
     int64_t opt_heavy_budget = 0;  // chunks per wave before it gives up; 0 = automatic
+    int64_t opt_scan_max = -1;  // n x positions up to which a batch is answered by the exact scan; -1 = automatic
     unsigned long long* d_amb_mask = nullptr;
     uint32_t* d_amb_cnt = nullptr;
     uint32_t* d_amb_s1 = nullptr;
@@ -732,6 +733,48 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     const bool fast = h->fast_active;  // GPU-built tree: the packet kernel is the only nn search
     const int qdepth = fast ? (int)h->fast_levels : h->kd.quad_depth;
     const uint32_t pstack = 3u * (uint32_t)(qdepth > 0 ? qdepth : 1) + 4u;
+    // Small batches.  A tree walk is a chain of dependent loads: ~2 ms for ONE far-field query on a
+    // 180k-vertex tree, whether a lane walks alone (strict kernel) or a wave walks for 64 sparse
+    // queries (their union is most of the tree).  While n x positions is small the exact scan of
+    // k_query_heavy (one wave per four queries, lanes over all vertices, no dependent loads) is
+    // both the shortest and the cheapest: 1000 queries on 180k vertices in ~0.1 ms instead of 2.3.
+    constexpr bool needs_nn = !(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST));
+    // Threshold on n x positions: the scan costs ~n x positions / 2.7e12 s, the tree-walking path has
+    // a floor that grows with the tree (0.25 ms at 4k positions, 2.2 ms at 190k: ~positions^0.57).
+    const double scan_max = h->opt_scan_max >= 0
+                                ? (double)h->opt_scan_max
+                                : 5.0e8 * std::pow((double)(M.kd_npos > 4000u ? M.kd_npos : 4000u) / 4000.0, 0.57);
+    if (needs_nn && M.kd_npos > 0 && n <= 0x7FFFFFFF && (double)n * (double)M.kd_npos <= scan_max) {
+        if (int rc = reserve_query_ws(h, 0, n)) return rc;
+        constexpr int HK = needs_nn ? KIND : Q_NN;
+        HIPC(hipMemsetAsync(h->d_fb_count, 0, 3 * sizeof(uint32_t), s));
+        const int64_t packs = (n + HEAVY_Q - 1) / HEAVY_Q;
+        // kinds with a tail: positions first, then one lane per query for ray parity + face distances
+        int32_t* pos = KIND == Q_NN ? nullptr : (int32_t*)(h->d_fb_list + h->fb_cap);
+        ProfScope prof{h, s};
+        if (int rc = prof.begin()) return rc;
+        if (packs <= 1024)  // few queries: 16 waves share each scan (the chain of one wave is ~0.4 ms at 190k)
+            k_query_heavy<HK, ROBUST, 16><<<(uint32_t)packs, 1024, 0, s>>>(
+                M, d_pts, nullptr, nullptr, trunc, d_out, h->d_fb_list, h->d_fb_count, (uint32_t)n, pos);
+        else
+            k_query_heavy<HK, ROBUST, 4><<<(uint32_t)(packs < 16384 ? packs : 16384), 256, 0, s>>>(
+                M, d_pts, nullptr, nullptr, trunc, d_out, h->d_fb_list, h->d_fb_count, (uint32_t)n, pos);
+        if (pos)
+            k_scan_finish<HK, ROBUST><<<(uint32_t)((n + 255) / 256), 256, 0, s>>>(M, d_pts, pos, (uint32_t)n, trunc,
+                                                                                 d_out);
+        if (int rc = prof.end(n)) return rc;
+        HIPC(hipGetLastError());
+        if (!fast) {  // what the scan could not decide (near ties failing the path check): exact emulation
+            const int64_t grid_pts = n < (int64_t)QBLOCK * 4096 ? n : (int64_t)QBLOCK * 4096;
+            if (int rc = launch_strict<KIND, ROBUST>(h, M, d_pts, h->d_fb_list, grid_pts, trunc, d_out,
+                                                     h->d_fb_count, s))
+                return rc;
+        }
+        if (h->opt_profile)
+            HIPC(hipMemcpyAsync(&h->last_fb, h->d_fb_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        h->last_heavy = (uint32_t)n;
+        return 0;
+    }
     const bool packet_any =
         KIND != Q_DETAIL && (fast || (sort_any && h->opt_packet && pstack * 132u <= 48u * 1024u));
     const int64_t fb_cap = packet_any ? (n < (1ll << 27) ? n : (1ll << 27)) : 0;
@@ -747,10 +790,10 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         if (!(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST))) {
             // queries of the waves that gave up (tail limiter): one wave per query; what is
             // still ambiguous afterwards joins the deferred list
-            const int64_t hw = deferred_pts < 8192 ? deferred_pts : 8192;
-            k_query_heavy<HK, ROBUST><<<(uint32_t)((hw + 3) / 4), 256, 0, s>>>(
+            const int64_t packs = (deferred_pts + HEAVY_Q - 1) / HEAVY_Q;
+            k_query_heavy<HK, ROBUST, 4><<<(uint32_t)(packs < 8192 ? packs : 8192), 256, 0, s>>>(
                 M, d_pts, h->d_fb_list + h->fb_cap, h->d_fb_count + 2, trunc, d_out, h->d_fb_list,
-                h->d_fb_count + flip);
+                h->d_fb_count + flip, 0u, nullptr);
             HIPC(hipGetLastError());
         }
         if (!fast) {
@@ -1066,6 +1109,10 @@ int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32
             if (v > 0 && (unsigned)v < hw) hw = (unsigned)v;
         }
         h->opt_build_threads = hw < 1 ? 1 : (hw > 16 ? 16 : hw);
+    }
+    if (const char* e = getenv("SDFHIP_SCAN_MAX")) {  // default of option "scan_max" (tests pin the tree paths with 0)
+        const long long v = atoll(e);
+        h->opt_scan_max = v < 0 ? -1 : v;
     }
     if (copy) {
         h->owned_verts.assign(verts, verts + 3 * (size_t)nv);
@@ -1389,6 +1436,8 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_build_threads = v < 1 ? 1 : v;
     else if (!strcmp(key, "packet"))
         h->opt_packet = v;
+    else if (!strcmp(key, "scan_max"))
+        h->opt_scan_max = v < 0 ? -1 : v;
     else if (!strcmp(key, "heavy_budget")) {
         if (v < 0 || v > 0x7FFFFFFF) return fail(SDFHIP_E_INVALID, "heavy_budget must be >= 0 (0 = automatic)");
         h->opt_heavy_budget = v;

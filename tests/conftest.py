@@ -8,6 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Small batches are answered by the exact scan (option "scan_max"); the parity tests are mostly small,
+# so by default they pin the tree-walking kernels (strict, packet) and tests/test_gpu_scan.py covers
+# the scan with the library's own default.
+os.environ.setdefault("SDFHIP_SCAN_MAX", "0")
+SCAN_MAX_DEFAULT = -1  # automatic
+
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 GOLDEN_NAMES = ["teapot", "torus", "boxframe", "cubegrid", "syntorus83", "icosphere3"]
 

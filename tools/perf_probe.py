@@ -19,6 +19,7 @@ ap.add_argument("--ray-mode", type=int, default=0)
 ap.add_argument("--noise", type=float, default=0.05)
 ap.add_argument("--group", type=int, default=0, help="packet_group option (0 = library default)")
 ap.add_argument("--heavy-budget", type=int, default=0)
+ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--rmin", type=float, default=0.0, help="drop points closer than this to the origin")
 a = ap.parse_args()
 if a.mesh.startswith("ico"):
@@ -47,6 +48,8 @@ if a.rmin > 0:
 n = pts.shape[0]
 if a.ray_mode:
     s.set_option("ray_mode", a.ray_mode)
+if a.chunk:
+    s.set_option("chunk", a.chunk)
 if a.heavy_budget:
     s.set_option("heavy_budget", a.heavy_budget)
 if a.nosort:
