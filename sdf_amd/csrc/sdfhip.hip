@@ -936,6 +936,17 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
     if (cap > n) cap = n;
     if (int rc = ensure_host_staging(h, cap)) return rc;
     const int64_t nchunks = (n + cap - 1) / cap;
+    if (nchunks == 1) {  // nothing to overlap: one stream, no helper thread (latency of small calls)
+        hipStream_t s = h->stream;
+        HIPC(hipMemcpyAsync(h->d_stage_in[0], pts, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+        if (int rc1 = run_query(h, kind, h->d_stage_in[0], n, trunc, h->d_stage_out[0], s)) {
+            (void)hipStreamSynchronize(s);
+            return rc1;
+        }
+        HIPC(hipMemcpyAsync(out, h->d_stage_out[0], osz * (size_t)n, hipMemcpyDeviceToHost, s));
+        HIPC(hipStreamSynchronize(s));
+        return 0;
+    }
     auto span = [&](int64_t c) { return (n - c * cap) < cap ? (n - c * cap) : cap; };
     int rc = 0;
     hipError_t e = hipSuccess;
