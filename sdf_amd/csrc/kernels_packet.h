@@ -33,6 +33,11 @@
 #define SDFK_PBLOCK 64
 #endif
 constexpr int PBLOCK = SDFK_PBLOCK;
+// 80 SGPRs or fewer admit 8 waves per SIMD, 82-96 only 7 (MI355X_MICROARCH.md "Residency"); the
+// compiler would take 90.  Measured: robust sdf kernel 16.3 -> 15.5 ms for 64M points, nn unchanged.
+#ifndef SDFK_PK_SGPR
+#define SDFK_PK_SGPR __attribute__((amdgpu_num_sgpr(80)))
+#endif
 
 
 // result of the packet pass for one lane
@@ -322,7 +327,7 @@ __device__ __forceinline__ float kd_path_max_bound(const MeshDev& M, float qx, f
 }
 
 template <int KIND, bool ROBUST>
-__global__ __launch_bounds__(PBLOCK) void k_query_packet(MeshDev M, const float* __restrict__ pts,
+__global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M, const float* __restrict__ pts,
                                                          const uint32_t* __restrict__ perm, int64_t n,
                                                          int trunc_aabb, void* __restrict__ out,
                                                          unsigned long long* __restrict__ amb_mask,
