@@ -24,14 +24,21 @@
 //     position of child 2's vertices (child 1 holds the positions below it).
 //   * nodes are emitted in DFS pre-order, near the order queries walk them.
 //
-// The recursion is task-parallel: after a node's own split its two ranges are independent, so
-// the top levels hand one child to another thread; sub-ranges are built into local arrays and
-// spliced into the global pre-order numbering afterwards.  The result is identical to the
-// serial build (it has to be: the numbering is part of the tie rule's data).
+// The build is parallel in two ways, both byte-identical to the serial recursion (they have to be:
+// the permutation and the numbering are part of the tie rule's data):
+//   * the top levels are split breadth-first, every split itself data-parallel (KdTeam): min/max
+//     and counts by blocks, and planeSplit's two Hoare passes as what they are — the k-th
+//     misplaced element from the left swaps with the k-th from the right;
+//   * the ranges below are independent: built concurrently into local arrays and spliced into
+//     the global pre-order numbering afterwards.
 #pragma once
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
-#include <future>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -65,6 +72,92 @@ constexpr uint32_t KD_FEAT_SHIFT = 29;
 constexpr uint32_t KD_REF_MASK = 0x1FFFFFFFu;  // strips leaf bit and feat bits
 constexpr uint32_t KD_MAX_POINTS = 1u << 23;   // padded positions (< 4 per vertex) fit 25 bits
 constexpr uint32_t KD_GROUP_LIMIT = 60;        // chunks of a group fit 4 bits
+
+// Fork-join helper of the builder: `workers` persistent threads.  They sleep on a condition
+// variable between builds and spin between the (many, short) phases of one build, where a
+// condition-variable wake-up per phase would cost more than the phase.
+class KdTeam {
+   public:
+    explicit KdTeam(int workers) {
+        for (int i = 0; i < workers; ++i) th_.emplace_back([this] { loop(); });
+    }
+    ~KdTeam() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    int size() const { return (int)th_.size() + 1; }
+    void begin() {  // wake the workers into spinning
+        {
+            std::lock_guard<std::mutex> l(m_);
+            awake_ = true;
+        }
+        cv_.notify_all();
+    }
+    void end() {  // back to sleep: a generation of its own that carries no job
+        std::lock_guard<std::mutex> l(m_);
+        awake_ = false;
+        const unsigned g = spin_.load(std::memory_order_relaxed) + 1u;
+        sleep_gen_.store(g, std::memory_order_relaxed);
+        spin_.store(g, std::memory_order_release);
+    }
+    // fn(b) for every b in [0, nb), dynamically shared among the workers and the caller
+    void run(int nb, const std::function<void(int)>& fn) {
+        if (nb <= 0) return;
+        if (th_.empty() || nb == 1) {
+            for (int b = 0; b < nb; ++b) fn(b);
+            return;
+        }
+        fn_ = &fn;
+        nb_ = nb;
+        next_.store(0, std::memory_order_relaxed);
+        done_.store(0, std::memory_order_relaxed);
+        spin_.fetch_add(1, std::memory_order_release);  // publish the job
+        work();
+        while (done_.load(std::memory_order_acquire) != (int)th_.size()) std::this_thread::yield();
+    }
+
+   private:
+    void work() {
+        for (;;) {
+            const int b = next_.fetch_add(1, std::memory_order_relaxed);
+            if (b >= nb_) break;
+            (*fn_)(b);
+        }
+    }
+    void loop() {
+        unsigned seen = 0;  // spin_'s initial value: a job published before this thread first looks still counts
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return awake_ || quit_; });
+                if (quit_) return;
+            }
+            for (;;) {  // spin while a build is running
+                const unsigned g = spin_.load(std::memory_order_acquire);
+                if (g == seen) {
+                    std::this_thread::yield();
+                    continue;
+                }
+                seen = g;  // every generation is handled once: a job (run waits for all workers) or end()
+                if (sleep_gen_.load(std::memory_order_relaxed) == g) break;
+                work();
+                done_.fetch_add(1, std::memory_order_release);
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    bool awake_ = false, quit_ = false;
+    std::atomic<unsigned> spin_{0}, sleep_gen_{0xFFFFFFFFu};
+    std::atomic<int> next_{0}, done_{0};
+    const std::function<void(int)>* fn_ = nullptr;
+    int nb_ = 0;
+};
 
 struct KdHost {
     std::vector<int32_t> vind;      // nanoflann's permutation (dense, size n)
@@ -108,7 +201,20 @@ struct KdHost {
     float at(int32_t i, int d) const { return p_[3 * (size_t)i + d]; }
     Cut choose_and_partition(int32_t* ind, int32_t count, const Box& box, float& cutval) const;
     uint32_t divide(Sub& out, int32_t left, int32_t right, Box& box, int level, bool in_group);
-    void divide_par(Sub& out, int32_t left, int32_t right, Box& box, int par_levels, int32_t cutoff);
+    // a node of the breadth-first top of the tree
+    struct Top {
+        int32_t left = 0, right = 0;
+        Box box;  // passed down (nanoflann.hpp:881-888); tight once its subtree is built
+        int feat = 0;
+        float cut = 0.f;
+        int32_t mid = 0;
+        int c1 = -1, c2 = -1;  // children in top_ (-1: this range is built by divide())
+        Sub sub;               // the built range (leaves of the top)
+    };
+    std::vector<Top> top_;
+    std::unique_ptr<KdTeam> team_;
+    void split_level(const std::vector<int>& frontier);
+    void assemble(int t, Sub& out);
     void splice(const Sub& s, uint32_t node_off, uint32_t pos_off);
     uint32_t quad_of(uint32_t ref, int level);
     std::vector<uint32_t> sub_first_, sub_count_;  // per binary node: first position, vertices
@@ -151,6 +257,16 @@ inline KdHost::Cut KdHost::choose_and_partition(int32_t* ind, int32_t count, con
             }
             float spread = mx - mn;
             if (spread > best_spread) feat = d, best_spread = spread, fmn = mn, fmx = mx;
+        }
+    }
+    if (best_spread < 0) {
+        // no dimension qualified (all spans zero: every point equal): nanoflann still clamps the
+        // cut to the elements of cutfeat = 0 (its second computeMinMax, nanoflann.hpp:936-939)
+        fmn = fmx = at(ind[0], 0);
+        for (int32_t k = 1; k < count; ++k) {
+            const float v = at(ind[k], 0);
+            if (v < fmn) fmn = v;
+            if (v > fmx) fmx = v;
         }
     }
     float cut = (box.lo[feat] + box.hi[feat]) / 2;
@@ -246,39 +362,200 @@ inline uint32_t KdHost::divide(Sub& out, int32_t left, int32_t right, Box& box, 
     return self;
 }
 
-// top levels: split here, build the two ranges concurrently (they touch disjoint parts of vind)
-inline void KdHost::divide_par(Sub& out, int32_t left, int32_t right, Box& box, int par_levels,
-                               int32_t cutoff) {
-    const int32_t count = right - left;
-    if (par_levels <= 0 || count <= cutoff || count <= (int32_t)KD_GROUP_LIMIT) {
-        out.root = divide(out, left, right, box, 0, false);
+// One level of the top of the tree: every node of `frontier` is split exactly as
+// choose_and_partition does it, all nodes at once and each node by blocks.
+//   planeSplit's first pass (nanoflann.hpp:971-985) moves `lo` up to the first element >= cut and
+//   `hi` down to the last one < cut, swaps, and repeats until they cross: the k-th misplaced
+//   element counted from the left meets the k-th counted from the right.  With lim1 = #(< cut)
+//   the misplaced ones are known without running the loop: left of lim1 those >= cut, right of
+//   it those < cut.  The second pass (986-1001) does the same for <= cut on [lim1, count).
+//   (The `!hi` guards only matter for unsigned indices: with hi == 0 the loop ends either way.)
+inline void KdHost::split_level(const std::vector<int>& frontier) {
+    struct Blk {
+        int node;
+        int32_t a, b;  // range within the node
+        float mn[3], mx[3];
+        int32_t n_lt = 0, n_le = 0;
+        std::vector<int32_t> L, R, E;
+    };
+    constexpr int32_t BLK = 8192;
+    std::vector<Blk> blk;
+    std::vector<int> first_blk(frontier.size() + 1, 0);
+    for (size_t f = 0; f < frontier.size(); ++f) {
+        const Top& T = top_[frontier[f]];
+        const int32_t count = T.right - T.left;
+        const int32_t nb = (count + BLK - 1) / BLK;
+        for (int32_t k = 0; k < nb; ++k) {
+            Blk B;
+            B.node = (int)f;
+            B.a = k * BLK;
+            B.b = (k + 1) * BLK < count ? (k + 1) * BLK : count;
+            blk.push_back(std::move(B));
+        }
+        first_blk[f + 1] = (int)blk.size();
+    }
+    const int nblk = (int)blk.size();
+    // A: min / max per dimension (exact, order independent)
+    team_->run(nblk, [&](int bi) {
+        Blk& B = blk[bi];
+        const int32_t* ind = vind.data() + top_[frontier[B.node]].left;
+        for (int d = 0; d < 3; ++d) B.mn[d] = B.mx[d] = at(ind[B.a], d);
+        for (int32_t k = B.a + 1; k < B.b; ++k)
+            for (int d = 0; d < 3; ++d) {
+                const float v = at(ind[k], d);
+                if (v < B.mn[d]) B.mn[d] = v;
+                if (v > B.mx[d]) B.mx[d] = v;
+            }
+    });
+    for (size_t f = 0; f < frontier.size(); ++f) {  // nanoflann.hpp:909-945
+        Top& T = top_[frontier[f]];
+        float mn[3], mx[3];
+        for (int d = 0; d < 3; ++d) mn[d] = blk[first_blk[f]].mn[d], mx[d] = blk[first_blk[f]].mx[d];
+        for (int bi = first_blk[f] + 1; bi < first_blk[f + 1]; ++bi)
+            for (int d = 0; d < 3; ++d) {
+                if (blk[bi].mn[d] < mn[d]) mn[d] = blk[bi].mn[d];
+                if (blk[bi].mx[d] > mx[d]) mx[d] = blk[bi].mx[d];
+            }
+        float span[3], max_span = T.box.hi[0] - T.box.lo[0];
+        for (int d = 0; d < 3; ++d) {
+            span[d] = T.box.hi[d] - T.box.lo[d];
+            if (span[d] > max_span) max_span = span[d];
+        }
+        const float EPS = 0.00001f;
+        float best_spread = -1;
+        int feat = 0;
+        for (int d = 0; d < 3; ++d)
+            if (span[d] > (1 - EPS) * max_span) {
+                const float spread = mx[d] - mn[d];
+                if (spread > best_spread) feat = d, best_spread = spread;
+            }
+        float cut = (T.box.lo[feat] + T.box.hi[feat]) / 2;
+        if (cut < mn[feat])
+            cut = mn[feat];
+        else if (cut > mx[feat])
+            cut = mx[feat];
+        T.feat = feat;
+        T.cut = cut;
+    }
+    // B: lim1 = #(< cut), lim2 = #(<= cut)
+    team_->run(nblk, [&](int bi) {
+        Blk& B = blk[bi];
+        const Top& T = top_[frontier[B.node]];
+        const int32_t* ind = vind.data() + T.left;
+        int32_t lt = 0, le = 0;
+        for (int32_t k = B.a; k < B.b; ++k) {
+            const float v = at(ind[k], T.feat);
+            lt += v < T.cut;
+            le += v <= T.cut;
+        }
+        B.n_lt = lt, B.n_le = le;
+    });
+    std::vector<int32_t> lim1(frontier.size(), 0), lim2(frontier.size(), 0);
+    for (size_t f = 0; f < frontier.size(); ++f)
+        for (int bi = first_blk[f]; bi < first_blk[f + 1]; ++bi) lim1[f] += blk[bi].n_lt, lim2[f] += blk[bi].n_le;
+    // C: the misplaced elements of the first pass, in ascending position
+    team_->run(nblk, [&](int bi) {
+        Blk& B = blk[bi];
+        const Top& T = top_[frontier[B.node]];
+        const int32_t* ind = vind.data() + T.left;
+        const int32_t l1 = lim1[B.node];
+        for (int32_t k = B.a; k < B.b; ++k) {
+            const bool lt = at(ind[k], T.feat) < T.cut;
+            if (k < l1) {
+                if (!lt) B.L.push_back(k);
+            } else if (lt) {
+                B.R.push_back(k);
+            }
+        }
+    });
+    // D: k-th from the left <-> k-th from the right
+    std::vector<std::vector<int32_t>> Ls(frontier.size()), Rs(frontier.size());
+    struct Job {
+        int node;
+        int32_t a, b;
+    };
+    std::vector<Job> jobs;
+    for (size_t f = 0; f < frontier.size(); ++f) {
+        for (int bi = first_blk[f]; bi < first_blk[f + 1]; ++bi) {
+            Ls[f].insert(Ls[f].end(), blk[bi].L.begin(), blk[bi].L.end());
+            Rs[f].insert(Rs[f].end(), blk[bi].R.begin(), blk[bi].R.end());
+        }
+        const int32_t m = (int32_t)Ls[f].size();  // == Rs[f].size()
+        for (int32_t a = 0; a < m; a += BLK) jobs.push_back({(int)f, a, a + BLK < m ? a + BLK : m});
+    }
+    team_->run((int)jobs.size(), [&](int j) {
+        const Job& J = jobs[j];
+        int32_t* ind = vind.data() + top_[frontier[J.node]].left;
+        const std::vector<int32_t>&Lp = Ls[J.node], &Rp = Rs[J.node];
+        const size_t m = Lp.size();
+        for (int32_t k = J.a; k < J.b; ++k) {
+            const int32_t l = Lp[k], r = Rp[m - 1 - (size_t)k];
+            const int32_t t = ind[l];
+            ind[l] = ind[r];
+            ind[r] = t;
+        }
+    });
+    // E: second pass on [lim1, count): elements <= cut there are == cut, normally a handful
+    team_->run(nblk, [&](int bi) {
+        Blk& B = blk[bi];
+        const Top& T = top_[frontier[B.node]];
+        const int32_t* ind = vind.data() + T.left;
+        const int32_t l1 = lim1[B.node];
+        for (int32_t k = B.a > l1 ? B.a : l1; k < B.b; ++k)
+            if (at(ind[k], T.feat) <= T.cut) B.E.push_back(k);
+    });
+    for (size_t f = 0; f < frontier.size(); ++f) {
+        Top& T = top_[frontier[f]];
+        int32_t* ind = vind.data() + T.left;
+        const int32_t count = T.right - T.left, l1 = lim1[f], l2 = lim2[f];
+        std::vector<int32_t> E;
+        for (int bi = first_blk[f]; bi < first_blk[f + 1]; ++bi) E.insert(E.end(), blk[bi].E.begin(), blk[bi].E.end());
+        // left of lim2: positions not in E are misplaced (ascending); right of it: those in E (descending)
+        size_t e = 0, r = E.size();
+        for (int32_t pos = l1; pos < l2; ++pos) {
+            if (e < E.size() && E[e] == pos) {
+                ++e;
+                continue;
+            }
+            --r;  // E[r] >= l2: there are exactly as many of them as gaps left of l2
+            const int32_t t = ind[pos];
+            ind[pos] = ind[E[r]];
+            ind[E[r]] = t;
+        }
+        if (l1 > count / 2)  // nanoflann.hpp:950-955
+            T.mid = l1;
+        else if (l2 < count / 2)
+            T.mid = l2;
+        else
+            T.mid = count / 2;
+    }
+}
+
+// the Sub tree of top node t, bottom-up (same shape divide()'s recursion would give it)
+inline void KdHost::assemble(int t, Sub& out) {
+    Top& T = top_[t];
+    if (T.c1 < 0) {
+        out = std::move(T.sub);
         out.total_nodes = (uint32_t)out.nodes.size();
         out.total_pos = out.npos;
         return;
     }
-    float cut;
-    const Cut c = choose_and_partition(vind.data() + left, count, box, cut);
     out.nodes.push_back({});
     out.c1.reset(new Sub());
     out.c2.reset(new Sub());
-    Box lb = box, rb = box;
-    lb.hi[c.feat] = cut;
-    rb.lo[c.feat] = cut;
-    auto fut = std::async(std::launch::async, [&]() {
-        divide_par(*out.c1, left, left + c.mid, lb, par_levels - 1, cutoff);
-    });
-    divide_par(*out.c2, left + c.mid, right, rb, par_levels - 1, cutoff);
-    fut.get();
+    assemble(T.c1, *out.c1);
+    assemble(T.c2, *out.c2);
+    const Box &lb = top_[T.c1].box, &rb = top_[T.c2].box;  // tight boxes of the children
     KdNodeH& nd = out.nodes[0];
-    nd.divlow = lb.hi[c.feat];
-    nd.divhigh = rb.lo[c.feat];
-    nd.ref1 = (uint32_t)c.feat << KD_FEAT_SHIFT;  // child refs are set when spliced
+    nd.divlow = lb.hi[T.feat];
+    nd.divhigh = rb.lo[T.feat];
+    nd.ref1 = (uint32_t)T.feat << KD_FEAT_SHIFT;  // child refs are set when spliced
     nd.ref2 = 0;
     for (int d = 0; d < 3; ++d)
         nd.lo1[d] = lb.lo[d], nd.hi1[d] = lb.hi[d], nd.lo2[d] = rb.lo[d], nd.hi2[d] = rb.hi[d];
     for (int d = 0; d < 3; ++d) {
-        box.lo[d] = lb.lo[d] < rb.lo[d] ? lb.lo[d] : rb.lo[d];
-        box.hi[d] = lb.hi[d] > rb.hi[d] ? lb.hi[d] : rb.hi[d];
+        T.box.lo[d] = lb.lo[d] < rb.lo[d] ? lb.lo[d] : rb.lo[d];
+        T.box.hi[d] = lb.hi[d] > rb.hi[d] ? lb.hi[d] : rb.hi[d];
     }
     out.total_nodes = 1 + out.c1->total_nodes + out.c2->total_nodes;
     out.total_pos = out.c1->total_pos + out.c2->total_pos;
@@ -332,13 +609,64 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads) {
             if (v > box.hi[d]) box.hi[d] = v;
         }
     for (int d = 0; d < 3; ++d) bbox[d] = box.lo[d], bbox[d + 3] = box.hi[d];
-    int par_levels = 0;
+    Sub top;
     if (threads > 1 && n >= 20000) {
+        int par_levels = 0;
         while ((1 << par_levels) < threads && par_levels < 6) ++par_levels;
         ++par_levels;  // ranges are uneven: a few more tasks than threads
+        const int32_t cutoff = (int32_t)(n / 64 + 1024);
+        if (!team_ || team_->size() != threads) team_.reset(new KdTeam(threads - 1));
+        team_->begin();
+        top_.clear();
+        top_.emplace_back();
+        top_[0].left = 0, top_[0].right = (int32_t)n, top_[0].box = box;
+        std::vector<int> frontier{0}, ranges;
+        for (int level = 0; !frontier.empty(); ++level) {
+            std::vector<int> split;
+            for (int t : frontier) {
+                const int32_t count = top_[t].right - top_[t].left;
+                if (level >= par_levels || count <= cutoff || count <= (int32_t)KD_GROUP_LIMIT)
+                    ranges.push_back(t);
+                else
+                    split.push_back(t);
+            }
+            if (!split.empty()) split_level(split);
+            frontier.clear();
+            for (int t : split) {
+                // (copies: emplace_back below may move the array)
+                const int32_t left = top_[t].left, right = top_[t].right, mid = top_[t].mid;
+                const Box pbox = top_[t].box;
+                const int feat = top_[t].feat;
+                const float cut = top_[t].cut;
+                for (int side = 0; side < 2; ++side) {
+                    top_.emplace_back();
+                    Top& C = top_.back();
+                    C.left = side ? left + mid : left;
+                    C.right = side ? right : left + mid;
+                    C.box = pbox;  // parent box narrowed at the cut (nanoflann.hpp:881-888)
+                    (side ? C.box.lo : C.box.hi)[feat] = cut;
+                    frontier.push_back((int)top_.size() - 1);
+                }
+                top_[t].c1 = (int)top_.size() - 2, top_[t].c2 = (int)top_.size() - 1;
+            }
+        }
+        // the ranges below the top are independent (disjoint parts of vind): largest first
+        std::sort(ranges.begin(), ranges.end(), [&](int x, int y) {
+            return top_[x].right - top_[x].left > top_[y].right - top_[y].left;
+        });
+        team_->run((int)ranges.size(), [&](int i) {
+            Top& T = top_[ranges[i]];
+            T.sub.root = divide(T.sub, T.left, T.right, T.box, 0, false);
+        });
+        team_->end();
+        assemble(0, top);
+        box = top_[0].box;
+        top_.clear();
+    } else {
+        top.root = divide(top, 0, (int32_t)n, box, 0, false);
+        top.total_nodes = (uint32_t)top.nodes.size();
+        top.total_pos = top.npos;
     }
-    Sub top;
-    divide_par(top, 0, (int32_t)n, box, par_levels, (int32_t)(n / 64 + 1024));
     nodes.resize(top.total_nodes);
     split.resize(top.total_nodes);
     pos_vert.assign((size_t)top.total_pos, -1);

@@ -66,7 +66,8 @@ int main() {
                 sdfk::KdHost a, b;
                 a.group_max = b.group_max = g;
                 a.build(p.data(), n, 1);
-                b.build(p.data(), n, 8);
+                b.build(p.data(), n, g == 16u ? 3 : (g == 32u ? 16 : 8));
+                b.build(p.data(), n, g == 16u ? 3 : (g == 32u ? 16 : 8));  // (a rebuild reuses the team)
                 a.build_quads();
                 b.build_quads();
                 bool ok = a.root_ref == b.root_ref && a.depth == b.depth && a.vind == b.vind &&

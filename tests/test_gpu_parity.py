@@ -169,6 +169,29 @@ def test_degenerate_vertex_sets_use_deep_trees():
     assert (s.nn(pts) == o.nn(pts)).all()
 
 
+def test_all_vertices_equal_and_large_parallel_build():
+    """(a) every vertex identical: all spans are zero, no split dimension qualifies and nanoflann clamps
+    the cut to the elements of dimension 0 (its second computeMinMax) -> halving splits; every query
+    is a many-way exact tie.  (b) a vertex set large enough for the data-parallel top of the host
+    build (>= 20000): the tree must still be nanoflann's."""
+    rng = np.random.default_rng(21)
+    v = np.tile(np.array([[0.25, -0.5, 0.125]], np.float32), (300, 1))
+    f = np.array([[0, 1, 2]], np.uint32)
+    q = rng.uniform(-1, 1, (20000, 3)).astype(np.float32)
+    s, o = SDF(v, f, robust=False), po.OracleSDF(v, f, False)
+    assert s.stats["kd_depth"] == o.kd_max_depth()
+    assert (s.nn(q) == o.nn(q)).all()
+    s.set_option("sort_queries", 0)
+    assert (s.nn(q) == o.nn(q)).all()
+    # (b) lattice with many equal coordinates (equal keys in every partition), shuffled
+    g = np.stack(np.meshgrid(*[np.arange(32)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    v = (g[rng.permutation(g.shape[0])] * 0.0625 - 1.0).astype(np.float32)
+    s, o = SDF(v, f, robust=False), po.OracleSDF(v, f, False)
+    assert s.stats["kd_depth"] == o.kd_max_depth()
+    q = np.concatenate([rng.uniform(-1.2, 1.2, (60000, 3)), rng.integers(-40, 40, (20000, 3)) * 0.03125]).astype(np.float32)
+    assert (s.nn(q) == o.nn(q)).all()
+
+
 def test_tie_heavy_lattices_packet_and_strict_paths():
     """integer-lattice vertices + half-integer / on-vertex queries: up to 8-way exact distance
     ties, resolved by nanoflann's visiting order.  Large batch -> packet pass (+ tie tracking,
