@@ -174,7 +174,11 @@ struct KdHost {
     int quad_depth = 0;
 
     // threads <= 1: serial.  Otherwise up to ~2*threads ranges are built concurrently.
-    void build(const float* pts, uint32_t n, int threads = 0);
+    // bbox_in: the result of bounds() on the same points, if the caller already has it.
+    void build(const float* pts, uint32_t n, int threads = 0, const float* bbox_in = nullptr);
+    // min xyz, max xyz of the points (the root box of the tree == the mesh AABB, sdf.cpp:36-37);
+    // zeros for n == 0.  Data-parallel for large n.
+    void bounds(const float* pts, uint32_t n, int threads, float out[6]);
     void build_quads();
 
    private:
@@ -587,7 +591,41 @@ inline void KdHost::splice(const Sub& s, uint32_t node_off, uint32_t pos_off) {
     for (size_t i = 0; i < s.pos_vert.size(); ++i) pos_vert[(size_t)pos_off + i] = s.pos_vert[i];
 }
 
-inline void KdHost::build(const float* pts, uint32_t n, int threads) {
+inline void KdHost::bounds(const float* pts, uint32_t n, int threads, float out[6]) {
+    for (int d = 0; d < 6; ++d) out[d] = 0.f;
+    if (n == 0) return;
+    constexpr uint32_t BLK = 16384;
+    const uint32_t nb = (threads > 1 && n >= 20000) ? (n + BLK - 1) / BLK : 1u;
+    std::vector<float> part(6 * (size_t)nb);
+    auto one = [&](int b) {
+        const uint32_t a = nb == 1 ? 0u : (uint32_t)b * BLK, e = nb == 1 ? n : (a + BLK < n ? a + BLK : n);
+        float lo[3] = {pts[3 * (size_t)a], pts[3 * (size_t)a + 1], pts[3 * (size_t)a + 2]};
+        float hi[3] = {lo[0], lo[1], lo[2]};
+        for (uint32_t k = a + 1; k < e; ++k)
+            for (int d = 0; d < 3; ++d) {
+                const float v = pts[3 * (size_t)k + d];
+                if (v < lo[d]) lo[d] = v;
+                if (v > hi[d]) hi[d] = v;
+            }
+        for (int d = 0; d < 3; ++d) part[6 * (size_t)b + d] = lo[d], part[6 * (size_t)b + 3 + d] = hi[d];
+    };
+    if (nb == 1) {
+        one(0);
+    } else {
+        if (!team_ || team_->size() != threads) team_.reset(new KdTeam(threads - 1));
+        team_->begin();
+        team_->run((int)nb, one);
+        team_->end();
+    }
+    for (int d = 0; d < 6; ++d) out[d] = part[d];
+    for (uint32_t b = 1; b < nb; ++b)
+        for (int d = 0; d < 3; ++d) {
+            if (part[6 * (size_t)b + d] < out[d]) out[d] = part[6 * (size_t)b + d];
+            if (part[6 * (size_t)b + 3 + d] > out[3 + d]) out[3 + d] = part[6 * (size_t)b + 3 + d];
+        }
+}
+
+inline void KdHost::build(const float* pts, uint32_t n, int threads, const float* bbox_in) {
     p_ = pts;
     vind.resize(n);
     for (uint32_t i = 0; i < n; ++i) vind[i] = (int32_t)i;
@@ -601,14 +639,11 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads) {
     for (int d = 0; d < 6; ++d) bbox[d] = 0;
     if (n == 0) return;
     Box box;
-    for (int d = 0; d < 3; ++d) box.lo[d] = box.hi[d] = at(0, d);
-    for (uint32_t k = 1; k < n; ++k)
-        for (int d = 0; d < 3; ++d) {
-            float v = at((int32_t)k, d);
-            if (v < box.lo[d]) box.lo[d] = v;
-            if (v > box.hi[d]) box.hi[d] = v;
-        }
-    for (int d = 0; d < 3; ++d) bbox[d] = box.lo[d], bbox[d + 3] = box.hi[d];
+    if (bbox_in)
+        for (int d = 0; d < 6; ++d) bbox[d] = bbox_in[d];
+    else
+        bounds(pts, n, threads, bbox);
+    for (int d = 0; d < 3; ++d) box.lo[d] = bbox[d], box.hi[d] = bbox[d + 3];
     Sub top;
     if (threads > 1 && n >= 20000) {
         int par_levels = 0;

@@ -344,11 +344,9 @@ int rend_query_host(sdfhip_renderer* r, int kind, const float* pts2, int64_t n, 
 
 extern "C" {
 
-int sdfhip_renderer_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, int width,
-                           int height, float fx, float fy, float cx, float cy, int copy, int device,
-                           sdfhip_renderer_t** out) {
-    if (!out) return fail(SDFHIP_E_INVALID, "out is null");
-    *out = nullptr;
+static int renderer_create_impl(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, int width,
+                                int height, float fx, float fy, float cx, float cy, int copy, int device,
+                                sdfhip_renderer_t** out) {
     if ((nv && !verts) || (nf && !faces)) return fail(SDFHIP_E_INVALID, "null verts/faces");
     if (width < 0 || height < 0) return fail(SDFHIP_E_INVALID, "negative image size");
     if (nv >= sdfk::KD_MAX_POINTS) return fail(SDFHIP_E_INVALID, "too many vertices (max %u)", sdfk::KD_MAX_POINTS);
@@ -364,6 +362,7 @@ int sdfhip_renderer_create(const float* verts, uint32_t nv, const uint32_t* face
     DevGuard g(device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", device);
     sdfhip_renderer* r = new sdfhip_renderer();
+    *out = r;  // the caller destroys it if anything below fails or throws
     r->device = device, r->own = copy != 0, r->nv = nv, r->nf = nf;
     r->width = width, r->height = height, r->fx = fx, r->fy = fy, r->cx = cx, r->cy = cy;
     if (copy) {
@@ -384,14 +383,24 @@ int sdfhip_renderer_create(const float* verts, uint32_t nv, const uint32_t* face
     A(dalloc(&r->d_fbox, 6 * (size_t)nf));
     A(dalloc(&r->d_bounds, 4));
     if (!rc) rc = rend_update(r);
-    if (rc) {
-        std::string keep = g_err;
-        sdfhip_renderer_destroy(r);
+    return rc;
+}
+
+int sdfhip_renderer_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, int width,
+                           int height, float fx, float fy, float cx, float cy, int copy, int device,
+                           sdfhip_renderer_t** out) {
+    if (!out) return fail(SDFHIP_E_INVALID, "out is null");
+    *out = nullptr;
+    const int rc = guarded([&]() -> int {
+        return renderer_create_impl(verts, nv, faces, nf, width, height, fx, fy, cx, cy, copy, device, out);
+    });
+    if (rc && *out) {
+        const std::string keep = g_err;
+        sdfhip_renderer_destroy(*out);
         g_err = keep;
-        return rc;
+        *out = nullptr;
     }
-    *out = r;
-    return 0;
+    return rc;
 }
 
 void sdfhip_renderer_destroy(sdfhip_renderer_t* r) {
@@ -413,29 +422,29 @@ int sdfhip_renderer_update(sdfhip_renderer_t* r) {
     std::lock_guard<std::mutex> lk(r->mu);
     DevGuard g(r->device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", r->device);
-    return rend_update(r);
+    return guarded([&]() -> int { return rend_update(r); });
 }
 
 int sdfhip_renderer_render_depth(sdfhip_renderer_t* r, float* out) {
-    return rend_query_host(r, R_DEPTH, nullptr, r ? (int64_t)r->width * r->height : 0, 0, out);
+    return guarded([&]() -> int { return rend_query_host(r, R_DEPTH, nullptr, r ? (int64_t)r->width * r->height : 0, 0, out); });
 }
 int sdfhip_renderer_render_mask(sdfhip_renderer_t* r, uint8_t* out) {
-    return rend_query_host(r, R_MASK, nullptr, r ? (int64_t)r->width * r->height : 0, 0, out);
+    return guarded([&]() -> int { return rend_query_host(r, R_MASK, nullptr, r ? (int64_t)r->width * r->height : 0, 0, out); });
 }
 int sdfhip_renderer_render_nn(sdfhip_renderer_t* r, int fill_outside, int32_t* out) {
-    return rend_query_host(r, R_VERTEX, nullptr, r ? (int64_t)r->width * r->height : 0, fill_outside, out);
+    return guarded([&]() -> int { return rend_query_host(r, R_VERTEX, nullptr, r ? (int64_t)r->width * r->height : 0, fill_outside, out); });
 }
 int sdfhip_renderer_depth(sdfhip_renderer_t* r, const float* pts2, int64_t n, float* out) {
     if (n > 0 && !pts2) return fail(SDFHIP_E_INVALID, "null points pointer");
-    return rend_query_host(r, R_DEPTH, pts2, n, 0, out);
+    return guarded([&]() -> int { return rend_query_host(r, R_DEPTH, pts2, n, 0, out); });
 }
 int sdfhip_renderer_contains(sdfhip_renderer_t* r, const float* pts2, int64_t n, uint8_t* out) {
     if (n > 0 && !pts2) return fail(SDFHIP_E_INVALID, "null points pointer");
-    return rend_query_host(r, R_MASK, pts2, n, 0, out);
+    return guarded([&]() -> int { return rend_query_host(r, R_MASK, pts2, n, 0, out); });
 }
 int sdfhip_renderer_nn(sdfhip_renderer_t* r, const float* pts2, int64_t n, int fill_outside, int32_t* out) {
     if (n > 0 && !pts2) return fail(SDFHIP_E_INVALID, "null points pointer");
-    return rend_query_host(r, R_VERTEX, pts2, n, fill_outside, out);
+    return guarded([&]() -> int { return rend_query_host(r, R_VERTEX, pts2, n, fill_outside, out); });
 }
 
 int sdfhip_renderer_query_device(sdfhip_renderer_t* r, int kind, const float* d_pts2, int64_t n,

@@ -73,6 +73,20 @@ static int fail(int code, const char* fmt, ...) {
                         __LINE__);                                                          \
     } while (0)
 
+// The C ABI never throws: host-side allocation (std::vector, std::thread) can.
+template <class F>
+static int guarded(F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(SDFHIP_E_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(SDFHIP_E_STATE, "internal error: %s", e.what());
+    } catch (...) {
+        return fail(SDFHIP_E_STATE, "internal error");
+    }
+}
+
 #include "kernels_query.h"
 
 #include "kernels_packet.h"
@@ -482,17 +496,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = h->stream;
     // mesh AABB (sdf.cpp:36-37; == the kd root box): needed by the device side before the tree
-    for (int d = 0; d < 6; ++d) h->aabb[d] = 0.f;
-    if (h->nv) {
-        float lo[3] = {h->h_verts[0], h->h_verts[1], h->h_verts[2]}, hi[3] = {lo[0], lo[1], lo[2]};
-        for (size_t i = 1; i < h->nv; ++i)
-            for (int d = 0; d < 3; ++d) {
-                const float v = h->h_verts[3 * i + d];
-                if (v < lo[d]) lo[d] = v;
-                if (v > hi[d]) hi[d] = v;
-            }
-        for (int d = 0; d < 3; ++d) h->aabb[d] = lo[d], h->aabb[d + 3] = hi[d];
-    }
+    h->kd.bounds(h->h_verts, h->nv, (int)h->opt_build_threads, h->aabb);
     if (h->robust && draw_R && !h->R_pinned) draw_rotation(h);
     // Device side (vertex upload, per-face precompute, LBVH order / refit) does not depend on
     // the kd-tree: it runs from a helper thread while this thread builds the tree.
@@ -521,7 +525,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     });
     // strict kd-tree on the host (sdf.cpp:32 kd_tree.rebuild())
     auto tk = std::chrono::steady_clock::now();
-    h->kd.build(h->h_verts, h->nv, (int)h->opt_build_threads);
+    h->kd.build(h->h_verts, h->nv, (int)h->opt_build_threads, h->aabb);
     h->last_kd_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk).count();
     // vertices in (padded) tree order; sentinel slots are far away: their distance is +inf
     const size_t npos = h->kd.pos_vert.size();
@@ -1089,10 +1093,8 @@ extern "C" {
 const char* sdfhip_last_error(void) { return g_err.c_str(); }
 const char* sdfhip_version(void) { return "sdfhip 0.1 (gfx950)"; }
 
-int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, int robust,
-                  int copy, int device, sdfhip_t** out) {
-    if (!out) return fail(SDFHIP_E_INVALID, "out is null");
-    *out = nullptr;
+static int create_impl(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, int robust,
+                       int copy, int device, sdfhip_t** out) {
     if ((nv && !verts) || (nf && !faces)) return fail(SDFHIP_E_INVALID, "null verts/faces");
     if (nv >= sdfk::KD_MAX_POINTS) return fail(SDFHIP_E_INVALID, "too many vertices (max %u)", sdfk::KD_MAX_POINTS);
     if (nf >= (1u << 30)) return fail(SDFHIP_E_INVALID, "too many faces");
@@ -1109,6 +1111,7 @@ int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", device);
 
     sdfhip_ctx* h = new sdfhip_ctx();
+    *out = h;  // the caller destroys it if anything below fails or throws
     h->device = device;
     h->robust = robust != 0;
     h->own = copy != 0;
@@ -1183,14 +1186,21 @@ int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32
     if (!rc && hipMemcpy(h->d_adj_off, h->adj_off.data(), sizeof(uint32_t) * ((size_t)nv + 1), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(SDFHIP_E_HIP, "upload of adjacency failed");
     if (!rc) rc = do_update(h, true);  // sdf.cpp:28 update(false): same work, kd built once
-    if (rc) {
-        std::string keep = g_err;
-        sdfhip_destroy(h);
+    return rc;
+}
+
+int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, int robust,
+                  int copy, int device, sdfhip_t** out) {
+    if (!out) return fail(SDFHIP_E_INVALID, "out is null");
+    *out = nullptr;
+    const int rc = guarded([&]() -> int { return create_impl(verts, nv, faces, nf, robust, copy, device, out); });
+    if (rc && *out) {
+        const std::string keep = g_err;
+        sdfhip_destroy(*out);
         g_err = keep;
-        return rc;
+        *out = nullptr;
     }
-    *out = h;
-    return 0;
+    return rc;
 }
 
 void sdfhip_destroy(sdfhip_t* h) {
@@ -1227,7 +1237,7 @@ int sdfhip_update(sdfhip_t* h) {
     std::lock_guard<std::mutex> lk(h->mu);
     DevGuard g(h->device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
-    return do_update(h, true);
+    return guarded([&]() -> int { return do_update(h, true); });
 }
 
 int sdfhip_update_from_device(sdfhip_t* h, const float* d_verts, void* stream) {
@@ -1240,7 +1250,7 @@ int sdfhip_update_from_device(sdfhip_t* h, const float* d_verts, void* stream) {
     HIPC(hipMemcpyAsync(h->owned_verts.data(), d_verts, sizeof(float) * 3 * (size_t)h->nv,
                         hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPC(hipStreamSynchronize((hipStream_t)stream));
-    return do_update(h, true);
+    return guarded([&]() -> int { return do_update(h, true); });
 }
 
 int sdfhip_set_raycast_axes(sdfhip_t* h, const float R[9], int pin) {
@@ -1267,26 +1277,26 @@ int sdfhip_get_raycast_axes(const sdfhip_t* h, float R[9]) {
 }
 
 int sdfhip_sdf(sdfhip_t* h, const float* p, int64_t n, int trunc, float* out) {
-    return run_query_host(h, Q_SDF, p, n, trunc, out);
+    return guarded([&]() -> int { return run_query_host(h, Q_SDF, p, n, trunc, out); });
 }
 int sdfhip_sdf_device(sdfhip_t* h, const float* p, int64_t n, int trunc, float* out, void* s) {
-    return run_query_dev(h, Q_SDF, p, n, trunc, out, s);
+    return guarded([&]() -> int { return run_query_dev(h, Q_SDF, p, n, trunc, out, s); });
 }
 int sdfhip_contains(sdfhip_t* h, const float* p, int64_t n, uint8_t* out) {
-    return run_query_host(h, Q_CONTAINS, p, n, 0, out);
+    return guarded([&]() -> int { return run_query_host(h, Q_CONTAINS, p, n, 0, out); });
 }
 int sdfhip_contains_device(sdfhip_t* h, const float* p, int64_t n, uint8_t* out, void* s) {
-    return run_query_dev(h, Q_CONTAINS, p, n, 0, out, s);
+    return guarded([&]() -> int { return run_query_dev(h, Q_CONTAINS, p, n, 0, out, s); });
 }
 int sdfhip_nn(sdfhip_t* h, const float* p, int64_t n, int32_t* out) {
-    return run_query_host(h, Q_NN, p, n, 0, out);
+    return guarded([&]() -> int { return run_query_host(h, Q_NN, p, n, 0, out); });
 }
 int sdfhip_nn_device(sdfhip_t* h, const float* p, int64_t n, int32_t* out, void* s) {
-    return run_query_dev(h, Q_NN, p, n, 0, out, s);
+    return guarded([&]() -> int { return run_query_dev(h, Q_NN, p, n, 0, out, s); });
 }
 int sdfhip_raycast_detail(sdfhip_t* h, const float* p, int64_t n, int32_t* out3) {
     if (h && !h->robust) return fail(SDFHIP_E_STATE, "raycast detail needs a robust handle");
-    return run_query_host(h, Q_DETAIL, p, n, 0, out3);
+    return guarded([&]() -> int { return run_query_host(h, Q_DETAIL, p, n, 0, out3); });
 }
 
 int sdfhip_robust(const sdfhip_t* h) { return h ? h->robust : 0; }
@@ -1315,7 +1325,7 @@ uint32_t* sdfhip_faces_mutable(sdfhip_t* h) {
 int sdfhip_surface_area(sdfhip_t* h, float* out) {
     if (!h || !out) return fail(SDFHIP_E_INVALID, "null handle/out");
     std::lock_guard<std::mutex> lk(h->mu);
-    if (int rc = fetch_face_host(h)) return rc;
+    if (int rc = guarded([&]() -> int { return fetch_face_host(h); })) return rc;
     float s = 0.f;
     for (float a : h->h_areas) s += a;
     *out = s;
@@ -1324,14 +1334,14 @@ int sdfhip_surface_area(sdfhip_t* h, float* out) {
 int sdfhip_face_areas(sdfhip_t* h, float* out) {
     if (!h || !out) return fail(SDFHIP_E_INVALID, "null handle/out");
     std::lock_guard<std::mutex> lk(h->mu);
-    if (int rc = fetch_face_host(h)) return rc;
+    if (int rc = guarded([&]() -> int { return fetch_face_host(h); })) return rc;
     std::memcpy(out, h->h_areas.data(), sizeof(float) * h->h_areas.size());
     return 0;
 }
 int sdfhip_face_normals(sdfhip_t* h, float* out) {
     if (!h || !out) return fail(SDFHIP_E_INVALID, "null handle/out");
     std::lock_guard<std::mutex> lk(h->mu);
-    if (int rc = fetch_face_host(h)) return rc;
+    if (int rc = guarded([&]() -> int { return fetch_face_host(h); })) return rc;
     std::memcpy(out, h->h_normals.data(), sizeof(float) * h->h_normals.size());
     return 0;
 }
@@ -1386,7 +1396,7 @@ int sdfhip_sample_surface_device(sdfhip_t* h, int64_t n, uint64_t seed, float* d
     std::lock_guard<std::mutex> lk(h->mu);
     DevGuard g(h->device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
-    return run_sample_surface(h, n, seed, d_out, (hipStream_t)stream);
+    return guarded([&]() -> int { return run_sample_surface(h, n, seed, d_out, (hipStream_t)stream); });
 }
 int sdfhip_sample_surface(sdfhip_t* h, int64_t n, uint64_t seed, float* out) {
     if (!h) return fail(SDFHIP_E_INVALID, "null handle");
@@ -1394,11 +1404,11 @@ int sdfhip_sample_surface(sdfhip_t* h, int64_t n, uint64_t seed, float* out) {
     std::lock_guard<std::mutex> lk(h->mu);
     DevGuard g(h->device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
-    if (n <= 0) return run_sample_surface(h, n, seed, nullptr, h->stream);
+    if (n <= 0) return guarded([&]() -> int { return run_sample_surface(h, n, seed, nullptr, h->stream); });
     float* d = nullptr;
     if (hipMalloc((void**)&d, sizeof(float) * 3 * (size_t)n) != hipSuccess)
         return fail(SDFHIP_E_NOMEM, "hipMalloc failed for %lld samples", (long long)n);
-    int rc = run_sample_surface(h, n, seed, d, h->stream);
+    int rc = guarded([&]() -> int { return run_sample_surface(h, n, seed, d, h->stream); });
     if (!rc) {
         hipError_t e = hipMemcpyAsync(out, d, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
