@@ -16,6 +16,10 @@
  *     passed as void*, NULL = the null stream) and are asynchronous on that stream.
  *   - a handle is bound to one GPU.  Query calls on one handle are serialised by the
  *     library (they share the handle's query workspace); `sdfhip_update` is exclusive.
+ *     This holds on the device too: a `_device` call on another stream than the previous
+ *     one, and `sdfhip_update`, are ordered after the previous call's kernels by an event,
+ *     so an asynchronous query is never overtaken by an update or by a query on a second
+ *     stream.
  *   - `n_threads` of the reference API (sdf.hpp:187-204) has no meaning on the GPU and is
  *     accepted and ignored by the façades above this ABI.
  *   - there is NO CPU fallback: without a usable HIP device `sdfhip_create` fails.

@@ -215,6 +215,13 @@ struct sdfhip_ctx {
     int64_t stage_cap = 0;     // points per staging slot
     int64_t opt_host_chunk = 0;  // 0 = automatic
     std::mutex mu;
+    // Device-side ordering between calls.  Host-side calls are serialised by `mu`, but the
+    // `_device` queries are asynchronous on the CALLER's stream and share the handle's workspace
+    // and structures: the next call on another stream (a query, or update() on `stream`) first
+    // waits for this event.
+    hipEvent_t ev_query = nullptr;
+    hipStream_t last_query_stream = nullptr;
+    bool query_pending = false;
     std::mt19937 rng;
     float last_update_ms = 0.f, last_kd_ms = 0.f;
     // optional live profiling of the query kernels (hipEvents on the launch stream)
@@ -492,9 +499,23 @@ int build_fast_tree(sdfhip_ctx* h) {
     return 0;
 }
 
+// order `s` after the last asynchronous query of this handle (no-op on the same stream)
+int wait_for_queries(sdfhip_ctx* h, hipStream_t s) {
+    if (h->query_pending && h->last_query_stream != s) HIPC(hipStreamWaitEvent(s, h->ev_query, 0));
+    return 0;
+}
+int mark_query(sdfhip_ctx* h, hipStream_t s) {
+    if (!h->ev_query) HIPC(hipEventCreateWithFlags(&h->ev_query, hipEventDisableTiming));
+    HIPC(hipEventRecord(h->ev_query, s));
+    h->last_query_stream = s;
+    h->query_pending = true;
+    return 0;
+}
+
 int do_update(sdfhip_ctx* h, bool draw_R) {
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = h->stream;
+    if (int rc = wait_for_queries(h, s)) return rc;  // queries still in flight read what update rewrites
     // mesh AABB (sdf.cpp:36-37; == the kd root box): needed by the device side before the tree
     h->kd.bounds(h->h_verts, h->nv, (int)h->opt_build_threads, h->aabb);
     if (h->robust && draw_R && !h->R_pinned) draw_rotation(h);
@@ -939,6 +960,7 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
     }
     if (cap > n) cap = n;
     if (int rc = ensure_host_staging(h, cap)) return rc;
+    if (int rc = wait_for_queries(h, h->stream)) return rc;  // (this call ends synchronised: nothing to mark)
     const int64_t nchunks = (n + cap - 1) / cap;
     if (nchunks == 1) {  // nothing to overlap: one stream, no helper thread (latency of small calls)
         hipStream_t s = h->stream;
@@ -1037,7 +1059,11 @@ int run_query_dev(sdfhip_ctx* h, int kind, const float* d_pts, int64_t n, int tr
     std::lock_guard<std::mutex> lk(h->mu);
     DevGuard g(h->device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
-    return run_query(h, kind, d_pts, n, trunc, d_out, (hipStream_t)stream);
+    if (int rc = wait_for_queries(h, (hipStream_t)stream)) return rc;
+    const int rc = run_query(h, kind, d_pts, n, trunc, d_out, (hipStream_t)stream);
+    if (n > 0)
+        if (int rc2 = mark_query(h, (hipStream_t)stream)) return rc ? rc : rc2;
+    return rc;
 }
 
 int fetch_face_host(sdfhip_ctx* h) {
@@ -1207,6 +1233,10 @@ void sdfhip_destroy(sdfhip_t* h) {
     if (!h) return;
     DevGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->ev_query) {
+        if (h->query_pending) (void)hipEventSynchronize(h->ev_query);  // a caller-stream query may still run
+        (void)hipEventDestroy(h->ev_query);
+    }
     void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_qn, h->d_kd_vind, h->d_adj_off,
                     h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
@@ -1266,6 +1296,7 @@ int sdfhip_set_raycast_axes(sdfhip_t* h, const float R[9], int pin) {
     if (!h->robust) return 0;
     DevGuard g(h->device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
+    if (int rc = wait_for_queries(h, h->stream)) return rc;
     if (int rc = update_device_side(h)) return rc;
     HIPC(hipStreamSynchronize(h->stream));
     return 0;
@@ -1396,7 +1427,11 @@ int sdfhip_sample_surface_device(sdfhip_t* h, int64_t n, uint64_t seed, float* d
     std::lock_guard<std::mutex> lk(h->mu);
     DevGuard g(h->device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
-    return guarded([&]() -> int { return run_sample_surface(h, n, seed, d_out, (hipStream_t)stream); });
+    return guarded([&]() -> int {
+        if (int rc = wait_for_queries(h, (hipStream_t)stream)) return rc;
+        if (int rc = run_sample_surface(h, n, seed, d_out, (hipStream_t)stream)) return rc;
+        return n > 0 ? mark_query(h, (hipStream_t)stream) : 0;  // update() must not overtake it
+    });
 }
 int sdfhip_sample_surface(sdfhip_t* h, int64_t n, uint64_t seed, float* out) {
     if (!h) return fail(SDFHIP_E_INVALID, "null handle");

@@ -259,6 +259,41 @@ def test_device_pointer_entry_points_with_torch():
     assert (s.nn(pts).cpu().numpy() == o.nn(h)).all()
 
 
+def test_async_queries_on_two_streams_and_update_do_not_race():
+    """`_device` calls are asynchronous on the caller's stream and share the handle's workspace:
+    a call on a second stream and update() must be ordered after the kernels of the call before."""
+    import torch
+    v, f = meshes.torus(150, 150)
+    R = meshes.random_rotation(5)
+    s = SDF(v, f)
+    s.set_raycast_axes(R)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    pa = torch.rand((3_000_000, 3), device="cuda", generator=g) * 2 - 1
+    pb = torch.rand((3_000_000, 3), device="cuda", generator=g) * 2 - 1
+    ref_a, ref_b = s(pa).clone(), s.nn(pb).clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            oa = s(pa)
+        with torch.cuda.stream(sb):
+            ob = s.nn(pb)
+        torch.cuda.synchronize()
+        assert same_float(oa.cpu().numpy(), ref_a.cpu().numpy()).all()
+        assert (ob == ref_b).all()
+    # an update right behind an asynchronous query must not change what that query reads
+    v2 = (v * 0.9).astype(np.float32)
+    with torch.cuda.stream(sa):
+        oa = s(pa)
+    s.vertices_mutable = v2
+    s.update()
+    torch.cuda.synchronize()
+    assert same_float(oa.cpu().numpy(), ref_a.cpu().numpy()).all()
+    o2 = po.OracleSDF(v2, f, True, R)
+    h = pa[:100000].cpu().numpy()
+    assert same_float(s(pa[:100000].contiguous()).cpu().numpy(), o2(h)).all()
+
+
 def test_large_mesh_properties_full_size():
     """BASELINE config-4 scale mesh: size-independent properties + a sampled oracle check."""
     v, f = meshes.torus(424, 424)
