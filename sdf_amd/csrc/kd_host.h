@@ -34,6 +34,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <functional>
@@ -172,6 +173,7 @@ struct KdHost {
     std::vector<KdQuadH> quads;  // 4-wide collapse of `nodes`, DFS pre-order
     uint32_t quad_root = KD_LEAF_BIT;
     int quad_depth = 0;
+    float t_top_ms = 0, t_ranges_ms = 0, t_splice_ms = 0;  // phases of the last parallel build
 
     // threads <= 1: serial.  Otherwise up to ~2*threads ranges are built concurrently.
     // bbox_in: the result of bounds() on the same points, if the caller already has it.
@@ -218,9 +220,22 @@ struct KdHost {
     std::vector<Top> top_;
     std::unique_ptr<KdTeam> team_;
     void split_level(const std::vector<int>& frontier);
+    struct SpliceJob {
+        const Sub* s;
+        uint32_t node_off, pos_off;
+    };
+    std::vector<SpliceJob> splice_jobs_;
+    std::vector<uint8_t> flag_;           // scratch of split_level, kept across builds
+    std::vector<int32_t> scrL_, scrR_;
     void assemble(int t, Sub& out);
     void splice(const Sub& s, uint32_t node_off, uint32_t pos_off);
-    uint32_t quad_of(uint32_t ref, int level);
+    struct QuadTask {
+        uint32_t ref, self;
+    };
+    uint32_t quad_of(uint32_t ref, int level, uint32_t self, int& max_level, int task_level,
+                     std::vector<QuadTask>* tasks);
+    std::vector<uint32_t> qsize_;  // per binary node: quad nodes of its subtree
+    uint32_t quad_size(uint32_t ref) const { return (ref & KD_LEAF_BIT) ? 0u : qsize_[ref & KD_REF_MASK]; }
     std::vector<uint32_t> sub_first_, sub_count_;  // per binary node: first position, vertices
     void subtree_extent(uint32_t ref, uint32_t& first, uint32_t& count) const {
         if (ref & KD_LEAF_BIT)
@@ -379,8 +394,8 @@ inline void KdHost::split_level(const std::vector<int>& frontier) {
         int node;
         int32_t a, b;  // range within the node
         float mn[3], mx[3];
-        int32_t n_lt = 0, n_le = 0;
-        std::vector<int32_t> L, R, E;
+        int32_t n_lt = 0, n_le = 0, nL = 0, nR = 0, offL = 0, offR = 0;
+        std::vector<int32_t> E;
     };
     constexpr int32_t BLK = 8192;
     std::vector<Blk> blk;
@@ -441,15 +456,19 @@ inline void KdHost::split_level(const std::vector<int>& frontier) {
         T.feat = feat;
         T.cut = cut;
     }
-    // B: lim1 = #(< cut), lim2 = #(<= cut)
+    // B: lim1 = #(< cut), lim2 = #(<= cut); the comparison results are kept for C (one indirect read less)
+    if (flag_.size() < vind.size()) flag_.resize(vind.size()), scrL_.resize(vind.size()), scrR_.resize(vind.size());
     team_->run(nblk, [&](int bi) {
         Blk& B = blk[bi];
         const Top& T = top_[frontier[B.node]];
         const int32_t* ind = vind.data() + T.left;
+        uint8_t* fl = flag_.data() + T.left;
         int32_t lt = 0, le = 0;
         for (int32_t k = B.a; k < B.b; ++k) {
             const float v = at(ind[k], T.feat);
-            lt += v < T.cut;
+            const bool l = v < T.cut;
+            fl[k] = l;
+            lt += l;
             le += v <= T.cut;
         }
         B.n_lt = lt, B.n_le = le;
@@ -457,46 +476,56 @@ inline void KdHost::split_level(const std::vector<int>& frontier) {
     std::vector<int32_t> lim1(frontier.size(), 0), lim2(frontier.size(), 0);
     for (size_t f = 0; f < frontier.size(); ++f)
         for (int bi = first_blk[f]; bi < first_blk[f + 1]; ++bi) lim1[f] += blk[bi].n_lt, lim2[f] += blk[bi].n_le;
-    // C: the misplaced elements of the first pass, in ascending position
+    // C: the misplaced elements of the first pass, in ascending position, block by block into scratch
     team_->run(nblk, [&](int bi) {
         Blk& B = blk[bi];
         const Top& T = top_[frontier[B.node]];
-        const int32_t* ind = vind.data() + T.left;
+        const uint8_t* fl = flag_.data() + T.left;
+        int32_t* L = scrL_.data() + T.left + B.a;
+        int32_t* R = scrR_.data() + T.left + B.a;
         const int32_t l1 = lim1[B.node];
-        for (int32_t k = B.a; k < B.b; ++k) {
-            const bool lt = at(ind[k], T.feat) < T.cut;
-            if (k < l1) {
-                if (!lt) B.L.push_back(k);
-            } else if (lt) {
-                B.R.push_back(k);
-            }
-        }
+        int32_t nl = 0, nr = 0;
+        const int32_t mid = l1 < B.a ? B.a : (l1 > B.b ? B.b : l1);
+        for (int32_t k = B.a; k < mid; ++k)
+            if (!fl[k]) L[nl++] = k;
+        for (int32_t k = mid; k < B.b; ++k)
+            if (fl[k]) R[nr++] = k;
+        B.nL = nl, B.nR = nr;
     });
-    // D: k-th from the left <-> k-th from the right
-    std::vector<std::vector<int32_t>> Ls(frontier.size()), Rs(frontier.size());
+    // D: k-th from the left <-> k-th from the right (block prefix tables instead of one long list)
     struct Job {
         int node;
-        int32_t a, b;
+        int32_t a, b, m;
     };
     std::vector<Job> jobs;
     for (size_t f = 0; f < frontier.size(); ++f) {
+        int32_t m = 0, mr = 0;
         for (int bi = first_blk[f]; bi < first_blk[f + 1]; ++bi) {
-            Ls[f].insert(Ls[f].end(), blk[bi].L.begin(), blk[bi].L.end());
-            Rs[f].insert(Rs[f].end(), blk[bi].R.begin(), blk[bi].R.end());
+            blk[bi].offL = m, blk[bi].offR = mr;
+            m += blk[bi].nL, mr += blk[bi].nR;
         }
-        const int32_t m = (int32_t)Ls[f].size();  // == Rs[f].size()
-        for (int32_t a = 0; a < m; a += BLK) jobs.push_back({(int)f, a, a + BLK < m ? a + BLK : m});
+        // (m == mr: as many elements >= cut left of lim1 as elements < cut right of it)
+        for (int32_t a = 0; a < m; a += BLK) jobs.push_back({(int)f, a, a + BLK < m ? a + BLK : m, m});
     }
     team_->run((int)jobs.size(), [&](int j) {
         const Job& J = jobs[j];
-        int32_t* ind = vind.data() + top_[frontier[J.node]].left;
-        const std::vector<int32_t>&Lp = Ls[J.node], &Rp = Rs[J.node];
-        const size_t m = Lp.size();
-        for (int32_t k = J.a; k < J.b; ++k) {
-            const int32_t l = Lp[k], r = Rp[m - 1 - (size_t)k];
-            const int32_t t = ind[l];
-            ind[l] = ind[r];
-            ind[r] = t;
+        const Top& T = top_[frontier[J.node]];
+        int32_t* ind = vind.data() + T.left;
+        const int b0 = first_blk[J.node], b1 = first_blk[J.node + 1];
+        // cursors: block holding the k-th L (ascending) and the (m-1-k)-th R
+        int bl = b0;
+        while (bl + 1 < b1 && blk[bl + 1].offL <= J.a) ++bl;
+        int32_t r = J.m - 1 - J.a;
+        int br = b1 - 1;
+        while (br > b0 && blk[br].offR > r) --br;
+        for (int32_t k = J.a; k < J.b; ++k, --r) {
+            while (k >= blk[bl].offL + blk[bl].nL) ++bl;
+            while (r < blk[br].offR) --br;
+            const int32_t lp = scrL_[(size_t)T.left + blk[bl].a + (k - blk[bl].offL)];
+            const int32_t rp = scrR_[(size_t)T.left + blk[br].a + (r - blk[br].offR)];
+            const int32_t t = ind[lp];
+            ind[lp] = ind[rp];
+            ind[rp] = t;
         }
     });
     // E: second pass on [lim1, count): elements <= cut there are == cut, normally a handful
@@ -581,14 +610,7 @@ inline void KdHost::splice(const Sub& s, uint32_t node_off, uint32_t pos_off) {
         splice(*s.c2, o2, p2);
         return;
     }
-    for (size_t i = 0; i < s.nodes.size(); ++i) {
-        KdNodeH nd = s.nodes[i];
-        nd.ref1 = shift_ref(nd.ref1, node_off, pos_off);
-        nd.ref2 = shift_ref(nd.ref2, node_off, pos_off);
-        nodes[node_off + i] = nd;
-        split[node_off + i] = s.split[i] + pos_off;
-    }
-    for (size_t i = 0; i < s.pos_vert.size(); ++i) pos_vert[(size_t)pos_off + i] = s.pos_vert[i];
+    splice_jobs_.push_back({&s, node_off, pos_off});
 }
 
 inline void KdHost::bounds(const float* pts, uint32_t n, int threads, float out[6]) {
@@ -648,9 +670,10 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads, const float
     if (threads > 1 && n >= 20000) {
         int par_levels = 0;
         while ((1 << par_levels) < threads && par_levels < 6) ++par_levels;
-        ++par_levels;  // ranges are uneven: a few more tasks than threads
-        const int32_t cutoff = (int32_t)(n / 64 + 1024);
+        par_levels += 2;  // ranges are uneven: ~4 tasks per thread, handed out largest first
+        const int32_t cutoff = (int32_t)(n / 256 + 1024);
         if (!team_ || team_->size() != threads) team_.reset(new KdTeam(threads - 1));
+        const auto tp0 = std::chrono::steady_clock::now();
         team_->begin();
         top_.clear();
         top_.emplace_back();
@@ -685,15 +708,23 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads, const float
                 top_[t].c1 = (int)top_.size() - 2, top_[t].c2 = (int)top_.size() - 1;
             }
         }
+        const auto tp1 = std::chrono::steady_clock::now();
         // the ranges below the top are independent (disjoint parts of vind): largest first
         std::sort(ranges.begin(), ranges.end(), [&](int x, int y) {
             return top_[x].right - top_[x].left > top_[y].right - top_[y].left;
         });
         team_->run((int)ranges.size(), [&](int i) {
             Top& T = top_[ranges[i]];
+            const size_t cnt = (size_t)(T.right - T.left);
+            T.sub.nodes.reserve(cnt / 4 + 16);
+            T.sub.split.reserve(cnt / 4 + 16);
+            T.sub.pos_vert.reserve(cnt + cnt / 4 + 64);
             T.sub.root = divide(T.sub, T.left, T.right, T.box, 0, false);
         });
         team_->end();
+        const auto tp2 = std::chrono::steady_clock::now();
+        t_top_ms = std::chrono::duration<float, std::milli>(tp1 - tp0).count();
+        t_ranges_ms = std::chrono::duration<float, std::milli>(tp2 - tp1).count();
         assemble(0, top);
         box = top_[0].box;
         top_.clear();
@@ -702,15 +733,41 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads, const float
         top.total_nodes = (uint32_t)top.nodes.size();
         top.total_pos = top.npos;
     }
+    const auto ts0 = std::chrono::steady_clock::now();
     nodes.resize(top.total_nodes);
     split.resize(top.total_nodes);
-    pos_vert.assign((size_t)top.total_pos, -1);
-    splice(top, 0, 0);
+    pos_vert.resize((size_t)top.total_pos);
+    splice_jobs_.clear();
+    splice(top, 0, 0);  // inner nodes of the top; the built ranges are copied below, concurrently
+    auto copy_range = [&](int j) {
+        const SpliceJob& J = splice_jobs_[j];
+        const Sub& r = *J.s;
+        for (size_t i = 0; i < r.nodes.size(); ++i) {
+            KdNodeH nd = r.nodes[i];
+            nd.ref1 = shift_ref(nd.ref1, J.node_off, J.pos_off);
+            nd.ref2 = shift_ref(nd.ref2, J.node_off, J.pos_off);
+            nodes[J.node_off + i] = nd;
+            split[J.node_off + i] = r.split[i] + J.pos_off;
+        }
+        for (size_t i = 0; i < r.pos_vert.size(); ++i) pos_vert[(size_t)J.pos_off + i] = r.pos_vert[i];
+    };
+    if (team_ && splice_jobs_.size() > 1) {
+        team_->begin();
+        team_->run((int)splice_jobs_.size(), copy_range);
+        team_->end();
+    } else {
+        for (size_t j = 0; j < splice_jobs_.size(); ++j) copy_range((int)j);
+    }
+    t_splice_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - ts0).count();
     depth = top.depth;
     root_ref = top.c1 ? 0u : top.root;
 }
 
-inline uint32_t KdHost::quad_of(uint32_t ref, int level) {
+// Quad nodes are numbered in DFS pre-order.  The number of quad nodes below every binary node is
+// known beforehand (qsize_), so a subtree's nodes have a fixed index range and subtrees can be
+// written concurrently: `tasks` != nullptr defers the subtrees at level `task_level`.
+inline uint32_t KdHost::quad_of(uint32_t ref, int level, uint32_t self, int& max_level, int task_level,
+                                std::vector<QuadTask>* tasks) {
     ref &= ~(3u << KD_FEAT_SHIFT);
     {   // a subtree of <= group_max vertices is one packet group (its block starts at a
         // multiple of 4: the builder opened it at exactly this subtree)
@@ -718,9 +775,11 @@ inline uint32_t KdHost::quad_of(uint32_t ref, int level) {
         subtree_extent(ref, first, count);
         if (count <= group_max) return KD_LEAF_BIT | ((first >> 2) << 4) | ((count + 3u) >> 2);
     }
-    if (level + 1 > quad_depth) quad_depth = level + 1;
-    const uint32_t self = (uint32_t)quads.size();
-    quads.push_back({});
+    if (tasks && level == task_level) {
+        tasks->push_back({ref, self});
+        return self;
+    }
+    if (level + 1 > max_level) max_level = level + 1;
     const float inf = __builtin_inff();
     KdQuadH q;
     for (int k = 0; k < 4; ++k) {
@@ -757,27 +816,59 @@ inline uint32_t KdHost::quad_of(uint32_t ref, int level) {
             used[k] = used[k + 1] = true;
         }
     }
+    uint32_t next = self + 1;  // pre-order: the children's subtrees follow, slot by slot
     for (int k = 0; k < 4; ++k)
-        if (used[k]) q.ref[k] = quad_of(gref[k], level + 1);
+        if (used[k]) {
+            q.ref[k] = quad_of(gref[k], level + 1, next, max_level, task_level, tasks);
+            next += quad_size(gref[k]);
+        }
     quads[self] = q;
     return self;
 }
 
 inline void KdHost::build_quads() {
-    // extents of every binary subtree (children follow their parent in pre-order)
+    // extents of every binary subtree and the number of quad nodes below it (children follow
+    // their parent in pre-order, so one reverse pass does)
     sub_first_.assign(nodes.size(), 0u);
     sub_count_.assign(nodes.size(), 0u);
+    qsize_.assign(nodes.size(), 0u);
     for (size_t i = nodes.size(); i-- > 0;) {
         uint32_t f1, c1, f2, c2;
-        subtree_extent(nodes[i].ref1 & ~(3u << KD_FEAT_SHIFT), f1, c1);
-        subtree_extent(nodes[i].ref2, f2, c2);
+        const uint32_t r1 = nodes[i].ref1 & ~(3u << KD_FEAT_SHIFT), r2 = nodes[i].ref2;
+        subtree_extent(r1, f1, c1);
+        subtree_extent(r2, f2, c2);
         sub_first_[i] = f1;
         sub_count_[i] = c1 + c2;
+        if (c1 + c2 <= group_max) continue;  // a group: no quad node
+        uint32_t q = 1;
+        const uint32_t rs[2] = {r1, r2}, cs[2] = {c1, c2};
+        for (int side = 0; side < 2; ++side)
+            if (cs[side] > group_max) {  // (then an internal node) its two children become slots
+                const KdNodeH& c = nodes[rs[side]];
+                q += quad_size(c.ref1 & ~(3u << KD_FEAT_SHIFT)) + quad_size(c.ref2);
+            }
+        qsize_[i] = q;
     }
-    quads.clear();
-    quads.reserve(nodes.size() / 2 + 8);
     quad_depth = 0;
-    quad_root = quad_of(root_ref, 0);
+    const uint32_t total = quad_size(root_ref);
+    quads.assign(total, KdQuadH{});
+    if (team_ && total >= 2048) {
+        std::vector<QuadTask> tasks;
+        int top_level = 0;
+        quad_root = quad_of(root_ref, 0, 0, top_level, 3, &tasks);
+        std::vector<int> lv(tasks.size(), 0);
+        team_->begin();
+        team_->run((int)tasks.size(), [&](int t) {
+            int ml = 0;
+            quad_of(tasks[t].ref, 3, tasks[t].self, ml, -1, nullptr);
+            lv[t] = ml;
+        });
+        team_->end();
+        quad_depth = top_level;
+        for (int v : lv) quad_depth = v > quad_depth ? v : quad_depth;
+    } else {
+        quad_root = quad_of(root_ref, 0, 0, quad_depth, -1, nullptr);
+    }
 }
 
 }  // namespace sdfk

@@ -73,7 +73,7 @@ int main() {
                 bool ok = a.root_ref == b.root_ref && a.depth == b.depth && a.vind == b.vind &&
                           a.pos_vert == b.pos_vert && a.split == b.split && a.nodes.size() == b.nodes.size() &&
                           !memcmp(a.nodes.data(), b.nodes.data(), a.nodes.size() * sizeof(sdfk::KdNodeH)) &&
-                          !memcmp(a.bbox, b.bbox, sizeof(a.bbox)) && a.quad_root == b.quad_root &&
+                          !memcmp(a.bbox, b.bbox, sizeof(a.bbox)) && a.quad_root == b.quad_root && a.quad_depth == b.quad_depth &&
                           a.quads.size() == b.quads.size() &&
                           !memcmp(a.quads.data(), b.quads.data(), a.quads.size() * sizeof(sdfk::KdQuadH));
                 if (!ok) { printf("MISMATCH n=%d mode=%d g=%u\n", n, mode, g); return 1; }

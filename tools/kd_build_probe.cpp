@@ -28,20 +28,29 @@ int main(int argc, char** argv) {
         a.build(p.data(), n, 1);
         best = std::min(best, ms(t0, std::chrono::steady_clock::now()));
     }
-    std::printf("serial            %7.2f ms\n", best);
+    {
+        auto t1 = std::chrono::steady_clock::now();
+        a.build_quads();
+        std::printf("serial            %7.2f ms   quads %.2f ms\n", best, ms(t1, std::chrono::steady_clock::now()));
+    }
     for (int k = 1; k < argc; ++k) {
         const int th = std::atoi(argv[k]);
         sdfk::KdHost b;
         best = 1e9;
+        double bestq = 1e9;
         for (int r = 0; r < 8; ++r) {
             auto t0 = std::chrono::steady_clock::now();
             b.build(p.data(), n, th);
             best = std::min(best, ms(t0, std::chrono::steady_clock::now()));
+            auto t1 = std::chrono::steady_clock::now();
+            b.build_quads();
+            bestq = std::min(bestq, ms(t1, std::chrono::steady_clock::now()));
         }
         const bool same = a.vind == b.vind && a.pos_vert == b.pos_vert && a.split == b.split &&
                           a.nodes.size() == b.nodes.size() &&
                           !std::memcmp(a.nodes.data(), b.nodes.data(), a.nodes.size() * sizeof(sdfk::KdNodeH));
-        std::printf("threads %2d        %7.2f ms   %s\n", th, best, same ? "identical" : "MISMATCH");
+        std::printf("threads %2d        %7.2f ms   %s   (last: top %.2f ranges %.2f splice %.2f)  quads %.2f ms\n", th, best,
+                    same ? "identical" : "MISMATCH", b.t_top_ms, b.t_ranges_ms, b.t_splice_ms, bestq);
     }
     return 0;
 }
