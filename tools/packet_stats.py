@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--mesh", default="torus"); ap.add_argument("--noise", type=float, default=0.0)
 ap.add_argument("--n", type=int, default=16_000_000); ap.add_argument("--grid", type=int, default=0)
 ap.add_argument("--fast-nn", type=int, default=0); ap.add_argument("--group", type=int, default=0)
+ap.add_argument("--repeat", type=int, default=1, help="every point R times in a row: a wave then holds 64/R distinct queries")
 a = ap.parse_args()
 v, f = meshes.torus(424, 424) if a.mesh == "torus" else meshes.icosphere(int(a.mesh[3:]), radius=0.8, noise=a.noise, seed=3)
 s = sdf_amd.SDF(v, f, robust=False)
@@ -23,6 +24,8 @@ if a.grid:
     pts = torch.stack(torch.meshgrid(t, t, t, indexing="ij"), -1).reshape(-1, 3).contiguous()
 else:
     pts = torch.rand((a.n, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(7)).mul_(2).sub_(1)
+if a.repeat > 1:
+    pts = pts.repeat_interleave(a.repeat, dim=0).contiguous()
 L = s._L
 st = (C.c_ulonglong * 8)()
 L.sdfhip_debug_packet_stats(st, 1)
