@@ -86,9 +86,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift,
     const uint32_t* __restrict__ hist, uint32_t ntiles, int vals_iota) {
-    __shared__ uint16_t cnt[RS_CHUNKS * 256];  // per (chunk, digit) counts -> offsets   24 KB
-    __shared__ uint32_t skey[RS_TILE];         // tile in digit order                   12 KB
-    __shared__ uint32_t sval[RS_TILE];         //                                       12 KB
+    // 24 KB used twice (6 blocks per CU instead of 3): first the per (chunk, digit) counts ->
+    // offsets, then — once every thread holds its slots in registers — the tile in digit order
+    __shared__ uint32_t lds_u[2 * RS_TILE];
+    static_assert(sizeof(uint16_t) * RS_CHUNKS * 256 <= sizeof(uint32_t) * 2 * RS_TILE, "cnt fits the tile buffers");
+    uint16_t* cnt = (uint16_t*)lds_u;
+    uint32_t* skey = lds_u;
+    uint32_t* sval = lds_u + RS_TILE;
     __shared__ uint32_t bstart[256];           // first local slot of each digit
     __shared__ uint32_t gbase[256];            // global base of each digit for this tile
     __shared__ uint32_t wsum[4];
@@ -136,14 +140,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
         gbase[dg] = hist[dg * ntiles + blockIdx.x];
     }
     __syncthreads();
-    for (int k = 0; k < RS_ITEMS; ++k) {
+    for (int k = 0; k < RS_ITEMS; ++k) {  // rank[] becomes the slot in the tile
         const int chunk = k * 4 + w;
+        const uint32_t dg = (key[k] >> shift) & 255u;
+        rank[k] = (uint16_t)(bstart[dg] + cnt[chunk * 256 + dg] + rank[k]);
+    }
+    __syncthreads();  // cnt is dead: its memory takes the tile
+    for (int k = 0; k < RS_ITEMS; ++k) {
         const uint32_t i = base + k * RS_THREADS + threadIdx.x;
         if (i < n) {
-            const uint32_t dg = (key[k] >> shift) & 255u;
-            const uint32_t slot = bstart[dg] + cnt[chunk * 256 + dg] + rank[k];
-            skey[slot] = key[k];
-            sval[slot] = val[k];
+            skey[rank[k]] = key[k];
+            sval[rank[k]] = val[k];
         }
     }
     __syncthreads();
