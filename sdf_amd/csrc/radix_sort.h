@@ -22,9 +22,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t* __restri
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * RS_TILE;
+    uint32_t key[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {  // all loads in flight before the first LDS atomic
+        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+        key[k] = keys[i < n ? i : n - 1];
+    }
+#pragma unroll
     for (int k = 0; k < RS_ITEMS; ++k) {
         const uint32_t i = base + k * RS_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&h[(key[k] >> shift) & 255u], 1u);
     }
     __syncthreads();
     hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
