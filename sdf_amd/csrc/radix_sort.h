@@ -168,7 +168,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
             const uint32_t kk = skey[slot];
             const uint32_t dg = (kk >> shift) & 255u;
             const uint32_t dst = gbase[dg] + (slot - bstart[dg]);
-            keys_out[dst] = kk;
+            if (keys_out) keys_out[dst] = kk;  // (the last pass of a sort whose keys nobody reads)
             vals_out[dst] = sval[slot];
         }
     }
@@ -206,8 +206,9 @@ struct RadixSorter {
     // sorts (keys, vals) ascending by the low `bits` bits of keys (8 bits per pass).  The result
     // is in *keys_out / *vals_out: the caller's buffers after an even number of passes, the
     // sorter's alternates after an odd number.  iota = 1: input values are taken as 0..n-1.
+    // keys_wanted = false: only the permutation is needed; the last pass then writes no keys.
     int sort(uint32_t* keys, uint32_t* vals, uint32_t n, int bits, int iota, hipStream_t s,
-             uint32_t** keys_out, uint32_t** vals_out) {
+             uint32_t** keys_out, uint32_t** vals_out, bool keys_wanted = true) {
         if (keys_out) *keys_out = keys;
         if (vals_out) *vals_out = vals;
         if (n == 0) return 0;
@@ -222,8 +223,8 @@ struct RadixSorter {
             const int shift = 8 * p;
             k_rs_hist<<<ntiles, RS_THREADS, 0, s>>>(ki, n, shift, hist, ntiles);
             exclusive_scan_u32(hist, nh, sums1, sums2, s);
-            k_rs_scatter<<<ntiles, RS_THREADS, 0, s>>>(ki, vi, ko, vo, n, shift, hist, ntiles,
-                                                       (p == 0 && iota) ? 1 : 0);
+            k_rs_scatter<<<ntiles, RS_THREADS, 0, s>>>(ki, vi, (p == passes - 1 && !keys_wanted) ? nullptr : ko, vo, n,
+                                                       shift, hist, ntiles, (p == 0 && iota) ? 1 : 0);
             uint32_t* t = ki;
             ki = ko, ko = t;
             t = vi;

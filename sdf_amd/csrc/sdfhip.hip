@@ -848,7 +848,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             k_query_morton<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(p, (uint32_t)m, h->d_qbounds,
                                                                        h->d_qkeys);
             uint32_t* sorted_perm = nullptr;
-            if (int rc = h->sorter.sort(h->d_qkeys, h->d_qperm, (uint32_t)m, 24, 1, s, nullptr, &sorted_perm))
+            if (int rc = h->sorter.sort(h->d_qkeys, h->d_qperm, (uint32_t)m, 24, 1, s, nullptr, &sorted_perm, false))
                 return rc;
             perm = sorted_perm;
         }
