@@ -72,14 +72,20 @@ __global__ void k_bounds_init(uint32_t* b) {
 }
 // flat float view of the [n,3] points: thread-contiguous float4 loads (coordinate = index % 3);
 // base pointers from hipMalloc / torch are 16-byte aligned, the tail is read scalar
-__global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, int64_t n, uint32_t* b) {
+// sample > 1: only one run of 64 groups (256 points, 3 KB) in every `sample` runs is read.  The
+// bounds only scale the Morton codes of the query sort (values outside are clamped into the border
+// cells), so a sample costs at most a little coherence, never a result.
+__global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, int64_t n, uint32_t* b,
+                                                int sample) {
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     const int64_t nf = 3 * n;
     const bool aligned = (((uintptr_t)pts) & 15) == 0;
     const int64_t ngroups = aligned ? nf / 12 : 0;  // 12 floats = 4 points = 3 float4
+    const int64_t nsampled = sample > 1 ? (ngroups / (64 * (int64_t)sample)) * 64 : ngroups;
     const float4* p4 = (const float4*)pts;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups;
-         g += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t gs = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gs < nsampled;
+         gs += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = sample > 1 ? (gs >> 6) * 64 * sample + (gs & 63) : gs;
         const float4 a = p4[3 * g], c = p4[3 * g + 1], d = p4[3 * g + 2];
         const float v[12] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
 #pragma unroll
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, i
             }
         }
     }
-    for (int64_t i = 12 * ngroups + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf;
+    for (int64_t i = 12 * ngroups + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf && sample <= 1;
          i += (int64_t)gridDim.x * blockDim.x) {
         const float x = pts[i];
         const int d = (int)(i % 3);

@@ -843,8 +843,11 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         const uint32_t* perm = nullptr;
         if (h->opt_sort && m >= sort_min) {
             k_bounds_init<<<1, 64, 0, s>>>(h->d_qbounds);
-            const int nb = (int)((m / 4 + 255) / 256 < 1024 ? (m / 4 + 255) / 256 + 1 : 1024);
-            k_bounds<<<nb, 256, 0, s>>>(p, m, h->d_qbounds);
+            // large batches: the bounds come from a strided sample (1/16 of the points, in 3 KB runs)
+            const int sample = m >= (8 << 20) ? 16 : 1;
+            const int64_t groups = m / 4 / sample;
+            const int nb = (int)((groups + 255) / 256 < 1024 ? (groups + 255) / 256 + 1 : 1024);
+            k_bounds<<<nb, 256, 0, s>>>(p, m, h->d_qbounds, sample);
             k_query_morton<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(p, (uint32_t)m, h->d_qbounds,
                                                                        h->d_qkeys);
             uint32_t* sorted_perm = nullptr;

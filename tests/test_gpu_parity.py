@@ -294,6 +294,31 @@ def test_async_queries_on_two_streams_and_update_do_not_race():
     assert same_float(s(pa[:100000].contiguous()).cpu().numpy(), o2(h)).all()
 
 
+def test_sampled_query_bounds_with_outliers():
+    """Batches of >= 8M points take the Morton bounds of the query sort from a strided sample; points
+    outside them (here: far outliers and non-finite points in runs the sample skips) are clamped into
+    the border cells, which may cost coherence but never a result."""
+    import torch
+    v, f = meshes.torus(83, 83)
+    R = meshes.random_rotation(8)
+    s = SDF(v, f)
+    s.set_raycast_axes(R)
+    n = 9_000_000
+    g = torch.Generator(device="cuda").manual_seed(31)
+    pts = torch.rand((n, 3), device="cuda", generator=g) * 2 - 1
+    special = torch.tensor([[50.0, -50.0, 50.0], [-1e6, 3.0, 0.0], [float("nan"), 0.0, 0.0],
+                            [0.0, float("inf"), 0.0], [7.0, 7.0, -7.0]], device="cuda")
+    idx = torch.tensor([300, 777, 5000, 4_000_300, n - 3], device="cuda")  # runs 1, 3, 19, ...: not sampled
+    pts[idx] = special
+    d, c, nn = s(pts), s.contains(pts), s.nn(pts)
+    sub = torch.cat([idx, torch.randint(0, n, (30000,), device="cuda", generator=g)])
+    h = pts[sub].cpu().numpy()
+    o = po.OracleSDF(v, f, True, R)
+    assert same_float(d[sub].cpu().numpy(), o(h)).all()
+    assert (c[sub].cpu().numpy() == o.contains(h)).all()
+    assert (nn[sub].cpu().numpy() == o.nn(h)).all()
+
+
 def test_large_mesh_properties_full_size():
     """BASELINE config-4 scale mesh: size-independent properties + a sampled oracle check."""
     v, f = meshes.torus(424, 424)
