@@ -418,15 +418,19 @@ __global__ void k_fb_compact(const unsigned long long* __restrict__ amb_mask,
                              const uint32_t* __restrict__ amb_scan, const uint32_t* __restrict__ perm,
                              int64_t n, uint32_t off, uint32_t* __restrict__ fb_list,
                              const uint32_t* __restrict__ base_in, uint32_t* __restrict__ total_out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t w = i >> 6;
-    const int lane = (int)(i & 63);
-    const unsigned long long m = amb_mask[w];
-    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // one thread per wave word: ambiguous queries are rare, most threads read one zero and leave
+    const int64_t nw = (n + 63) >> 6;
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    unsigned long long m = amb_mask[w];
     const uint32_t base = *base_in + amb_scan[w];
-    if ((m >> lane) & 1ull) fb_list[base + (uint32_t)__popcll(m & lt)] = off + perm[i];
-    if (i == n - 1) *total_out = base + (uint32_t)__popcll(m);
+    if (w == nw - 1) *total_out = base + (uint32_t)__popcll(m);
+    uint32_t k = 0;
+    while (m) {
+        const int lane = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        fb_list[base + k++] = off + perm[64 * w + lane];
+    }
 }
 
 // The exact scan.  Answers (a) the queries of the waves that gave up in the packet pass (heavy

@@ -872,7 +872,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
                 continue;
             }
             exclusive_scan_u32(h->d_amb_cnt, (uint32_t)((m + 63) / 64), h->d_amb_s1, h->d_amb_s2, s);
-            k_fb_compact<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(
+            k_fb_compact<<<(uint32_t)(((m + 63) / 64 + 255) / 256), 256, 0, s>>>(
                 h->d_amb_mask, h->d_amb_cnt, perm, m, (uint32_t)off, h->d_fb_list, h->d_fb_count + flip,
                 h->d_fb_count + (flip ^ 1));
             HIPC(hipGetLastError());
