@@ -199,6 +199,9 @@ def main():
             ms.append((time.perf_counter() - t1) * 1e3)
         extra["grid256_ms"] = min(ms)
         extra["grid256_inside"] = int((go > 0).sum().item())
+    # update() in steady state (the construction-time one also allocates): same vertices, twice
+    for _ in range(2):
+        s.update()
     extra["update_ms"] = s.stats["last_update_ms"]
     extra["kd_build_ms"] = s.stats["last_kd_build_ms"]
     line = {

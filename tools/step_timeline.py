@@ -10,7 +10,8 @@ j = idx
 while j > 0 and "k_bounds_init" not in rows[j]["Kernel_Name"]:
     j -= 1
 k = idx
-while k + 1 < len(rows) and "k_bounds_init" not in rows[k + 1]["Kernel_Name"] and k - idx < 12:
+while (k + 1 < len(rows) and "k_bounds_init" not in rows[k + 1]["Kernel_Name"] and k - idx < 12
+       and "k_face_precompute" not in rows[k + 1]["Kernel_Name"]):
     k += 1
 t0 = int(rows[j]["Start_Timestamp"]); prev = t0; busy = 0
 for r in rows[j:k + 1]:
