@@ -74,6 +74,11 @@ __device__ __forceinline__ int kd_dfs_first(const MeshDev& M, float qx, float qy
     return pa < pb ? pa : pb;
 }
 
+__device__ __forceinline__ float fmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -271,6 +276,185 @@ __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float 
     }
 }
 
+// =========================================================================================
+// Approximate first pass (strict mode).  The walk above spends 10 VALU per (query, vertex) on the
+// reference's exact arithmetic although almost every vertex it meets is NOT the nearest one.
+// Here a slot costs 4: with the vertex's squared norm in the padding word of kd_pts4,
+//     a(v) = fma(-2qx, vx, fma(-2qy, vy, fma(-2qz, vz, |v|^2)))  ~  D(v) - |q|^2
+// orders the vertices of one lane like nanoflann's fp32 distance D(v) up to a known error: with
+// u = 2^-24, S = max|v|^2 + 2 sum_i |q_i| max|v_i| and Q = |q|^2 (fp32 Qf),
+//     |a(v) + Qf - d^2(v)|  <=  u (4 S + 3 Q) =: Ea      (three roundings of partial sums <= S, the
+//                                                        rounding of |v|^2, the error of Qf)
+//     D(v) = d^2(v) (1 + t), |t| <= 5.01 u               (nanoflann.hpp:432-440, five roundings)
+// so  lower(a) = (a + Qf - Ea)(1 - 8u)  <=  D(v)  <=  (a + Qf + Ea)(1 + 8u) = upper(a)   (constants
+// rounded up; Ea is computed with 5 S + 4 Q).  Per lane the walk keeps the four smallest GROUP
+// minima B1 <= B2 <= B3 <= B4 of a() and the groups of the first three.  Pruning uses upper(B1)*c^2,
+// an upper bound of what the exact walk would use, so every vertex the exact walk needs is met.
+// Afterwards each lane evaluates EXACTLY (reference arithmetic, tie rules of the exact walk) the
+// groups whose minimum could still be the nearest: H1, and Hk while lower(Bk) <= upper(B1).
+// Every vertex outside them has D >= lower(B_next) > upper(B1) >= the exact minimum b found
+// inside them, strictly: b is the global minimum, no outside vertex ties with it, and
+// lower(B_next) is a lower bound of the distance of every outside vertex — which is all the
+// decision logic needs of `s`.  A fourth candidate group defers the query to the strict kernel.
+// =========================================================================================
+struct ApproxLane {
+    float B1, B2, B3, B4;  // smallest group minima of a(), ascending
+    uint32_t H1, H2, H3;   // refs of the groups of B1..B3 (H_NONE: none)
+    bool bailed;
+};
+
+__device__ __forceinline__ ApproxLane kd_nearest_packet_approx(const MeshDev& M, float qx, float qy, float qz,
+                                                               float Qe, float cm, const PacketStack stk) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const float INF = __builtin_inff();
+    const float X2 = -2.f * qx, Y2 = -2.f * qy, Z2 = -2.f * qz;
+    float B1 = INF, B2 = INF, B3 = INF, B4 = INF;
+    uint32_t H1 = H_NONE, H2 = H_NONE, H3 = H_NONE;
+    uint32_t cur = M.kd_qroot;
+    uint32_t sp = 0;
+    uint32_t work = 0;
+    SDFK_COUNT(0, 1);
+    for (;;) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        bool need_pop = false;
+        if (!(cur & KD_LEAF)) {
+            SDFK_COUNT(1, 1);
+            const float* Q = (const float*)(M.kd_qn + 8 * (size_t)cur);
+            const uint32_t r0 = __float_as_uint(Q[24]), r1 = __float_as_uint(Q[25]),
+                           r2 = __float_as_uint(Q[26]), r3 = __float_as_uint(Q[27]);
+            const float thr = fmaxf(B1 + Qe, 0.f) * cm;  // >= (exact best so far) * c^2
+            const float lb0 = box_lb(qx, qy, qz, Q[0], Q[1], Q[2], Q[3], Q[4], Q[5]);
+            const float lb1 = box_lb(qx, qy, qz, Q[6], Q[7], Q[8], Q[9], Q[10], Q[11]);
+            const float lb2 = box_lb(qx, qy, qz, Q[12], Q[13], Q[14], Q[15], Q[16], Q[17]);
+            const float lb3 = box_lb(qx, qy, qz, Q[18], Q[19], Q[20], Q[21], Q[22], Q[23]);
+            const uint32_t act = (__ballot(lb0 <= thr) != 0ull ? 1u : 0u) |
+                                 (__ballot(lb1 <= thr) != 0ull ? 2u : 0u) |
+                                 (__ballot(lb2 <= thr) != 0ull ? 4u : 0u) |
+                                 (__ballot(lb3 <= thr) != 0ull ? 8u : 0u);
+            if (act == 0u) {
+                need_pop = true;
+            } else if ((act & (act - 1u)) == 0u) {
+                cur = act == 1u ? r0 : (act == 2u ? r1 : (act == 4u ? r2 : r3));
+            } else {
+                const uint32_t u0 = __float_as_uint(lb0), u1 = __float_as_uint(lb1),
+                               u2 = __float_as_uint(lb2), u3 = __float_as_uint(lb3);
+                const bool a_first = (int)__popcll(__ballot(min(u0, u1) <= min(u2, u3))) >= 32;
+                const bool s01 = (int)__popcll(__ballot(u0 <= u1)) >= 32;
+                const bool s23 = (int)__popcll(__ballot(u2 <= u3)) >= 32;
+                uint32_t last = 0;
+#define SDFK_PK_PUSH(K)                                              \
+    if (act & (1u << K)) {                                           \
+        stk.lb[sp * 64u + lane] = (uint16_t)(u##K >> 16);            \
+        stk.ref[sp] = r##K;                                          \
+        last = r##K;                                                 \
+        ++sp;                                                        \
+    }
+#define SDFK_PK_ORDER(A, B, C, D) { SDFK_PK_PUSH(D) SDFK_PK_PUSH(C) SDFK_PK_PUSH(B) SDFK_PK_PUSH(A) }
+                if (a_first) {
+                    if (s01) {
+                        if (s23) SDFK_PK_ORDER(0, 1, 2, 3) else SDFK_PK_ORDER(0, 1, 3, 2)
+                    } else {
+                        if (s23) SDFK_PK_ORDER(1, 0, 2, 3) else SDFK_PK_ORDER(1, 0, 3, 2)
+                    }
+                } else {
+                    if (s01) {
+                        if (s23) SDFK_PK_ORDER(2, 3, 0, 1) else SDFK_PK_ORDER(3, 2, 0, 1)
+                    } else {
+                        if (s23) SDFK_PK_ORDER(2, 3, 1, 0) else SDFK_PK_ORDER(3, 2, 1, 0)
+                    }
+                }
+#undef SDFK_PK_ORDER
+#undef SDFK_PK_PUSH
+                --sp;
+                cur = last;
+            }
+        } else {
+            const uint32_t nch = cur & 15u;
+            const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
+            work += nch;
+            SDFK_COUNT(2, 1);
+            SDFK_COUNT(3, nch);
+            if (nch) {
+                const u32x16* C = (const u32x16*)__builtin_assume_aligned(M.kd_pts4 + first, 64);
+                float gm = INF;  // (a NaN never enters: fminf keeps the other operand)
+                for (uint32_t ci = 0; ci < nch; ++ci) {
+                    const u32x16 A = C[ci];
+#define SDFK_APX_SLOT(O_)                                                                  \
+    __builtin_fmaf(X2, __uint_as_float(A[O_]),                                             \
+                   __builtin_fmaf(Y2, __uint_as_float(A[O_ + 1]),                          \
+                                  __builtin_fmaf(Z2, __uint_as_float(A[O_ + 2]), __uint_as_float(A[O_ + 3]))))
+                    // 12 FMA + 2 v_min3 per chunk (a NaN operand is dropped by min3 as by min)
+                    const float a0 = SDFK_APX_SLOT(0), a1 = SDFK_APX_SLOT(4), a2 = SDFK_APX_SLOT(8),
+                                a3 = SDFK_APX_SLOT(12);
+                    gm = fmin3(gm, a0, a1);
+                    gm = fmin3(gm, a2, a3);
+#undef SDFK_APX_SLOT
+                }
+                // sorted insert of this group's minimum into B1..B4 (+ the groups of the first three)
+                const bool c1 = gm < B1, c2 = gm < B2, c3 = gm < B3;
+                H3 = c2 ? H2 : (c3 ? cur : H3);
+                H2 = c1 ? H1 : (c2 ? cur : H2);
+                H1 = c1 ? cur : H1;
+                float t = fmaxf(B1, gm);
+                B1 = fminf(B1, gm);
+                float t2 = fmaxf(B2, t);
+                B2 = fminf(B2, t);
+                t = fmaxf(B3, t2);
+                B3 = fminf(B3, t2);
+                B4 = fminf(B4, t);
+            }
+            need_pop = true;
+        }
+        if (need_pop) {
+            const uint32_t thr16 = __float_as_uint(fmaxf(B1 + Qe, 0.f) * cm) >> 16;
+            const bool over = work > M.heavy_budget;
+            if (over) sp = 0;
+            for (;;) {
+                if (sp == 0) return ApproxLane{B1, B2, B3, B4, H1, H2, H3, over};
+                --sp;
+                SDFK_COUNT(5, 1);
+                const uint32_t l16 = stk.lb[sp * 64u + lane];
+                const uint32_t r = stk.ref[sp];
+                if (__ballot(l16 <= thr16) != 0ull) {
+                    cur = r;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+// exact evaluation of one packet group for one lane (second phase of the approximate pass): the
+// reference's metric, strict `<`, and among exact ties the vertex nanoflann's DFS meets first
+__device__ __forceinline__ void exact_group(const MeshDev& M, float qx, float qy, float qz, uint32_t ref,
+                                            uint32_t& b, uint32_t& s2, uint32_t& pos) {
+    const uint32_t first = ((ref & sdfk::KD_REF_MASK) >> 4) << 2, nch = ref & 15u;
+    for (uint32_t c = 0; c < nch; ++c) {  // a chunk at a time: its four loads are in flight together
+        const float4* P = M.kd_pts4 + first + 4u * c;
+        const float4 P0 = P[0], P1 = P[1], P2 = P[2], P3 = P[3];
+        uint32_t du[4];
+#define SDFK_EX_D(J, V)                                                        \
+    {                                                                          \
+        const float dx = qx - V.x, dy = qy - V.y, dz = qz - V.z;               \
+        du[J] = __float_as_uint((dx * dx + dy * dy) + dz * dz);                \
+    }
+        SDFK_EX_D(0, P0) SDFK_EX_D(1, P1) SDFK_EX_D(2, P2) SDFK_EX_D(3, P3)
+#undef SDFK_EX_D
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t idx = first + 4u * c + j;
+            if (__builtin_expect(du[j] == b && pos != H_NONE, 0)) {
+                if ((uint32_t)kd_dfs_first(M, qx, qy, qz, (int)pos, (int)idx) == idx) pos = idx;
+            }
+            s2 = min(s2, max(du[j], b));
+            if (du[j] < b) {
+                b = du[j];
+                pos = idx;
+            }
+        }
+    }
+}
+
 // The exact tree position behind PacketBest::h: a group ref is resolved by finding the group's
 // one vertex at distance b (per lane, once per query).
 __device__ __forceinline__ int packet_resolve(const MeshDev& M, float qx, float qy, float qz, float bf,
@@ -326,7 +510,7 @@ __device__ __forceinline__ float kd_path_max_bound(const MeshDev& M, float qx, f
     return worst_bound;
 }
 
-template <int KIND, bool ROBUST>
+template <int KIND, bool ROBUST, bool APPROX>
 __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M, const float* __restrict__ pts,
                                                          const uint32_t* __restrict__ perm, int64_t n,
                                                          int trunc_aabb, void* __restrict__ out,
@@ -354,7 +538,22 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
         if ((threadIdx.x & 63) == 0) amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
         return;
     }
-    const PacketBest pb = kd_nearest_packet(M, p.x, p.y, p.z, stk);
+    PacketBest pb;
+    ApproxLane A;
+    float Qf = 0.f, Ea = 0.f;
+    if (APPROX) {
+        // error model of a() for this lane (see kd_nearest_packet_approx)
+        const float u = 5.9604645e-8f;  // 2^-24
+        const float Vx = fmaxf(fabsf(M.bb[0]), fabsf(M.bb[3])), Vy = fmaxf(fabsf(M.bb[1]), fabsf(M.bb[4])),
+                    Vz = fmaxf(fabsf(M.bb[2]), fabsf(M.bb[5]));
+        const float S = ((Vx * Vx + Vy * Vy) + Vz * Vz) + 2.f * ((fabsf(p.x) * Vx + fabsf(p.y) * Vy) + fabsf(p.z) * Vz);
+        Qf = (p.x * p.x + p.y * p.y) + p.z * p.z;
+        Ea = u * (5.f * S + 4.f * Qf);
+        A = kd_nearest_packet_approx(M, p.x, p.y, p.z, Qf + Ea, (1.f + 8.f * u) * M.amb_c2, stk);
+        pb.bailed = A.bailed;
+    } else {
+        pb = kd_nearest_packet(M, p.x, p.y, p.z, stk);
+    }
     if (pb.bailed) {  // wave-uniform: every query of this wave goes to the heavy list (absolute indices)
         const unsigned long long vm = __ballot(valid);
         const uint32_t lane = threadIdx.x & 63u;
@@ -373,8 +572,30 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
     //  (2) otherwise measure it: every bound tested on the way to pb.h is <= the distance of
     //      any other vertex (>= pb.s; == b for an exact tie, where pb.h is the first met);
     //  (3) else defer to the strict kernel (exact emulation).
-    const int pos = packet_resolve(M, p.x, p.y, p.z, pb.b, pb.h);
+    int pos;
     bool amb = false;
+    if (APPROX) {
+        // second phase: the groups whose minimum could be the nearest vertex, exactly
+        const float u = 5.9604645e-8f;
+        const float k1p = 1.f + 8.f * u, k1m = 1.f - 8.f * u;
+        const float x1 = A.B1 + (Qf + Ea);
+        const float U = fmaxf(fmaxf(x1 * k1p, x1), 0.f);  // >= D of B1's vertex >= the exact minimum
+        const float y2 = (A.B2 + Qf) - Ea, y3 = (A.B3 + Qf) - Ea, y4 = (A.B4 + Qf) - Ea;
+        const float L2 = fminf(y2 * k1m, y2), L3 = fminf(y3 * k1m, y3), L4 = fminf(y4 * k1m, y4);  // <= D outside
+        const bool n2 = !(L2 > U), n3 = n2 && !(L3 > U), n4 = n3 && !(L4 > U);
+        uint32_t b = 0x7F7FFFFFu, s2 = 0x7F7FFFFFu, hp = H_NONE;
+        if (A.H1 != H_NONE && !n4) {
+            exact_group(M, p.x, p.y, p.z, A.H1, b, s2, hp);
+            if (n2) exact_group(M, p.x, p.y, p.z, A.H2, b, s2, hp);
+            if (n3) exact_group(M, p.x, p.y, p.z, A.H3, b, s2, hp);
+        }
+        const float s_out = n3 ? L4 : (n2 ? L3 : L2);  // every vertex outside the evaluated groups is farther
+        pb.b = __uint_as_float(b);
+        pb.s = fminf(__uint_as_float(s2), s_out);
+        pos = hp == H_NONE ? -1 : (int)hp;  // (-1: nothing finite, or a fourth candidate group: deferred below)
+    } else {
+        pos = packet_resolve(M, p.x, p.y, p.z, pb.b, pb.h);
+    }
     if (!M.fast) {
         if (valid && (!(pb.s > pb.b * M.amb_c) || !(pb.b >= 1e-30f))) {
             amb = true;
@@ -388,7 +609,13 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
         }
         if (pos < 0) amb = true;
     }
-    {   // ambiguous lanes of this wave, in sorted order: compacted (stably) by k_fb_compact so
+    if (APPROX) {
+        // what the approximate pass cannot settle (a fourth candidate group, no finite distance, a
+        // window the path check does not clear) goes to the exact scan of k_query_heavy, which
+        // takes the same decision with exact (b, s, h) and defers to the strict kernel itself
+        if (valid && amb) heavy_list[atomicAdd(heavy_cnt, 1u)] = off + (uint32_t)src;
+        if ((threadIdx.x & 63) == 0) amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
+    } else {   // ambiguous lanes of this wave, in sorted order: compacted (stably) by k_fb_compact so
         // that the strict fallback kernel still sees Morton-coherent waves
         const unsigned long long m = __ballot(valid && amb);
         SDFK_COUNT(7, __popcll(m));

@@ -165,6 +165,8 @@ struct sdfhip_ctx {
     uint32_t* d_amb_s1 = nullptr;
     uint32_t* d_amb_s2 = nullptr;
     int64_t opt_packet = 1;
+    int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
+    bool approx_ok = false;   // decided by every update(): see approx_pays()
     int64_t opt_build_threads = 1;
     uint32_t* d_adj_off = nullptr;
     int32_t* d_adj_faces = nullptr;
@@ -499,6 +501,29 @@ int build_fast_tree(sdfhip_ctx* h) {
     return 0;
 }
 
+// The approximate first pass of the packet kernel orders vertices by a() = |v|^2 - 2 q.v, whose
+// absolute error ~ 5u S (S = max|v|^2 + 2 sum |q_i| max|v_i|, u = 2^-24) does not shrink with the
+// distance between neighbouring vertices.  Every group whose minimum lies within 2E of the best
+// is re-evaluated exactly, a fourth one sends the query to the exact scan — results never depend
+// on it, the time does.  Expected number of vertices in that window for a query near a surface of
+// vertex density rho: lambda = rho * pi * 2E.  It pays while lambda is small: not for meshes far
+// from the origin against their size (S large), nor for very dense ones.  rho is taken from the
+// surface of the AABB, |q_i| ~ max|v_i|; both crude, the threshold is generous.
+bool approx_pays(const sdfhip_ctx* h) {
+    if (h->nv < 64) return false;
+    double V[3], e[3];
+    for (int d = 0; d < 3; ++d) {
+        V[d] = std::fmax(std::fabs((double)h->aabb[d]), std::fabs((double)h->aabb[d + 3]));
+        e[d] = (double)h->aabb[d + 3] - (double)h->aabb[d];
+    }
+    const double S = 3.0 * (V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
+    const double E = 5.9604644775390625e-8 * 5.0 * S;
+    const double area = 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
+    if (!(area > 0.0) || !std::isfinite(area) || !std::isfinite(S)) return false;
+    const double lambda = (double)h->nv / area * 3.141592653589793 * 2.0 * E;
+    return lambda <= 0.3;
+}
+
 // order `s` after the last asynchronous query of this handle (no-op on the same stream)
 int wait_for_queries(sdfhip_ctx* h, hipStream_t s) {
     if (h->query_pending && h->last_query_stream != s) HIPC(hipStreamWaitEvent(s, h->ev_query, 0));
@@ -518,6 +543,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     if (int rc = wait_for_queries(h, s)) return rc;  // queries still in flight read what update rewrites
     // mesh AABB (sdf.cpp:36-37; == the kd root box): needed by the device side before the tree
     h->kd.bounds(h->h_verts, h->nv, (int)h->opt_build_threads, h->aabb);
+    h->approx_ok = approx_pays(h);
     if (h->robust && draw_R && !h->R_pinned) draw_rotation(h);
     // Device side (vertex upload, per-face precompute, LBVH order / refit) does not depend on
     // the kd-tree: it runs from a helper thread while this thread builds the tree.
@@ -557,10 +583,13 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
         for (size_t i = 0; i < nalloc; ++i) {
             const int32_t vi = i < npos ? h->kd.pos_vert[i] : -1;
             if (vi < 0) {
-                dst[4 * i] = dst[4 * i + 1] = dst[4 * i + 2] = dst[4 * i + 3] = 3.0e38f;
+                dst[4 * i] = dst[4 * i + 1] = dst[4 * i + 2] = 3.0e38f;
+                dst[4 * i + 3] = __builtin_inff();  // a() of a sentinel is +inf or NaN, never a minimum
             } else {
                 const float* src = h->h_verts + 3 * (size_t)vi;
-                dst[4 * i] = src[0], dst[4 * i + 1] = src[1], dst[4 * i + 2] = src[2], dst[4 * i + 3] = 3.0e38f;
+                dst[4 * i] = src[0], dst[4 * i + 1] = src[1], dst[4 * i + 2] = src[2];
+                // |v|^2 for the approximate first pass of the packet kernel, rounded once
+                dst[4 * i + 3] = (float)(((double)src[0] * src[0] + (double)src[1] * src[1]) + (double)src[2] * src[2]);
             }
         }
     });
@@ -862,9 +891,16 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             constexpr int PK = KIND == Q_DETAIL ? Q_NN : KIND;
             ProfScope prof{h, s};  // the dominant kernel, one event pair per launch
             if (int rc = prof.begin()) return rc;
-            k_query_packet<PK, ROBUST><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, lds, s>>>(
-                M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, pstack, (uint32_t)off,
-                h->d_fb_list + h->fb_cap, h->d_fb_count + 2);
+            // strict mode: approximate first pass + exact second phase (kernels_packet.h); the GPU-built
+            // tree of fast_nn has no strict kernel behind it and keeps the exact walk
+            if (!fast && (h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0))
+                k_query_packet<PK, ROBUST, true><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, lds, s>>>(
+                    M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, pstack, (uint32_t)off,
+                    h->d_fb_list + h->fb_cap, h->d_fb_count + 2);
+            else
+                k_query_packet<PK, ROBUST, false><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, lds, s>>>(
+                    M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, pstack, (uint32_t)off,
+                    h->d_fb_list + h->fb_cap, h->d_fb_count + 2);
             if (int rc = prof.end(m)) return rc;
             if (fast) {  // no near-tie deferral in this mode, only the heavy list
                 HIPC(hipGetLastError());
@@ -1152,6 +1188,10 @@ static int create_impl(const float* verts, uint32_t nv, const uint32_t* faces, u
             if (v > 0 && (unsigned)v < hw) hw = (unsigned)v;
         }
         h->opt_build_threads = hw < 1 ? 1 : (hw > 16 ? 16 : hw);
+    }
+    if (const char* e = getenv("SDFHIP_APPROX")) {  // default of option "approx" (tests run both packet walks)
+        const long long v = atoll(e);
+        h->opt_approx = v < 0 ? -1 : (v ? 1 : 0);
     }
     if (const char* e = getenv("SDFHIP_SCAN_MAX")) {  // default of option "scan_max" (tests pin the tree paths with 0)
         const long long v = atoll(e);
@@ -1495,6 +1535,8 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_build_threads = v < 1 ? 1 : v;
     else if (!strcmp(key, "packet"))
         h->opt_packet = v;
+    else if (!strcmp(key, "approx"))
+        h->opt_approx = v < 0 ? -1 : (v ? 1 : 0);
     else if (!strcmp(key, "scan_max"))
         h->opt_scan_max = v < 0 ? -1 : v;
     else if (!strcmp(key, "heavy_budget")) {

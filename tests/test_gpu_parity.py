@@ -12,6 +12,14 @@ from sdf_amd import SDF, meshes
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["1", "0"], ids=["approx", "exact"])
+def packet_walk(request, monkeypatch):
+    """every test of this module runs with both walks of the packet pass: the approximate first
+    pass + exact second phase (forced on, whatever the automatic criterion says) and the exact walk"""
+    monkeypatch.setenv("SDFHIP_APPROX", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module", params=GOLDEN_NAMES)
 def gold(request):
     g = load_golden(request.param)
@@ -292,6 +300,22 @@ def test_async_queries_on_two_streams_and_update_do_not_race():
     o2 = po.OracleSDF(v2, f, True, R)
     h = pa[:100000].cpu().numpy()
     assert same_float(s(pa[:100000].contiguous()).cpu().numpy(), o2(h)).all()
+
+
+def test_mesh_far_from_the_origin():
+    """a() = |v|^2 - 2 q.v loses its resolution when the mesh sits far from the origin against its size:
+    the approximate pass (forced on here; the automatic criterion turns it off) must then hand its
+    queries to the exact scan instead of answering wrongly."""
+    v, f = meshes.torus(60, 60)
+    v = (v + np.array([100.0, -50.0, 25.0])).astype(np.float32)
+    R = meshes.random_rotation(12)
+    rng = np.random.default_rng(13)
+    pts = (rng.uniform(-1.2, 1.2, (30000, 3)) + np.array([100.0, -50.0, 25.0])).astype(np.float32)
+    s = SDF(v, f)
+    s.set_raycast_axes(R)
+    o = po.OracleSDF(v, f, True, R)
+    assert (s.nn(pts) == o.nn(pts)).all()
+    assert same_float(s(pts), o(pts)).all()
 
 
 def test_sampled_query_bounds_with_outliers():
