@@ -217,6 +217,7 @@ int sdfhip_host_free(void* p);
 /* Tuning knobs (no counterpart). key: "sort_queries" (0/1, default 1: Morton-sort query
  * chunks of >= sort_min points), "sort_min", "sort_min_contains" (the same threshold for robust contains(),
  * default 12M: below it the ray walk runs on the caller's order), "chunk" (points per internal chunk), "packet" (0: strict kernel only),
+ * "approx" (packet pass: approximate first pass + exact second phase; -1 automatic (default), 0 off, 1 on; results are identical either way),
  * "scan_max" (batches with points x padded vertices up to this value are answered by the exact one-wave-per-query
  * scan instead of a tree walk; -1 = automatic (the default: ~5e8 x (vertices / 4000)^0.57), 0 = never), "heavy_budget" (chunks of four vertices a wave of the packet pass may evaluate before its queries go
  * to the one-wave-per-query kernel; 0 = automatic: 1/8 of the tree), "fast_nn" (0/1, applies at the next update: the vertex tree is built on the GPU, no host kd-tree;
