@@ -546,7 +546,7 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
         const float u = 5.9604645e-8f;  // 2^-24
         const float Vx = fmaxf(fabsf(M.bb[0]), fabsf(M.bb[3])), Vy = fmaxf(fabsf(M.bb[1]), fabsf(M.bb[4])),
                     Vz = fmaxf(fabsf(M.bb[2]), fabsf(M.bb[5]));
-        const float S = ((Vx * Vx + Vy * Vy) + Vz * Vz) + 2.f * ((fabsf(p.x) * Vx + fabsf(p.y) * Vy) + fabsf(p.z) * Vz);
+        const float S = M.vmax2 + 2.f * ((fabsf(p.x) * Vx + fabsf(p.y) * Vy) + fabsf(p.z) * Vz);
         Qf = (p.x * p.x + p.y * p.y) + p.z * p.z;
         Ea = u * (5.f * S + 4.f * Qf);
         A = kd_nearest_packet_approx(M, p.x, p.y, p.z, Qf + Ea, (1.f + 8.f * u) * M.amb_c2, stk);

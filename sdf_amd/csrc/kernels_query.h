@@ -28,6 +28,7 @@ struct MeshDev {
     uint32_t kd_npos;       // padded tree positions (sentinel slots included)
     uint32_t heavy_budget;  // packet pass: a wave that has evaluated more chunks than this gives up
     float amb_c, amb_c2;
+    float vmax2;  // max |v|^2 (approximate first pass)
     // adjacency + face geometry
     const uint32_t* adj_off;
     const int32_t* adj_faces;

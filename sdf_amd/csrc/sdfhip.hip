@@ -167,6 +167,7 @@ struct sdfhip_ctx {
     int64_t opt_packet = 1;
     int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
     bool approx_ok = false;   // decided by every update(): see approx_pays()
+    float vmax2 = 0.f;        // max |v|^2 over the vertices, rounded up (strict mode)
     int64_t opt_build_threads = 1;
     uint32_t* d_adj_off = nullptr;
     int32_t* d_adj_faces = nullptr;
@@ -577,7 +578,8 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     // vertices in (padded) tree order; sentinel slots are far away: their distance is +inf
     const size_t npos = h->kd.pos_vert.size();
     const size_t nalloc = npos + 16;
-    auto fill = std::async(std::launch::async, [h, npos, nalloc]() {
+    auto fill = std::async(std::launch::async, [h, npos, nalloc]() -> float {
+        float vmax2 = 0.f;  // max |v|^2 (rounded up below): the error model of the approximate pass
         h->perm_pts4.resize(4 * nalloc);
         float* dst = h->perm_pts4.data();
         for (size_t i = 0; i < nalloc; ++i) {
@@ -590,12 +592,14 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
                 dst[4 * i] = src[0], dst[4 * i + 1] = src[1], dst[4 * i + 2] = src[2];
                 // |v|^2 for the approximate first pass of the packet kernel, rounded once
                 dst[4 * i + 3] = (float)(((double)src[0] * src[0] + (double)src[1] * src[1]) + (double)src[2] * src[2]);
+                if (dst[4 * i + 3] > vmax2) vmax2 = dst[4 * i + 3];
             }
         }
+        return vmax2;
     });
     auto tq0 = std::chrono::steady_clock::now();
     h->kd.build_quads();
-    fill.get();
+    h->vmax2 = std::nextafter(fill.get(), FLT_MAX);
     auto tq1 = std::chrono::steady_clock::now();
     const int rc_dev = dev_side.get();
     auto tq2 = std::chrono::steady_clock::now();
@@ -667,6 +671,7 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.heavy_budget = h->opt_heavy_budget > 0 ? (uint32_t)h->opt_heavy_budget
                                              : (M.kd_npos / 32u > 4096u ? M.kd_npos / 32u : 4096u);
     M.amb_c = h->amb_c;
+    M.vmax2 = h->vmax2;
     M.amb_c2 = h->amb_c2;
     M.adj_off = h->d_adj_off;
     M.adj_faces = h->d_adj_faces;
