@@ -165,7 +165,7 @@ def main():
     achieved = BYTES_PER_EVAL * pts_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "k_query_packet<Q_SDF,robust>", "kernel_ms_avg": k_ms,
+                "kernel": "k_query_packet<Q_SDF,robust,approx>", "kernel_ms_avg": k_ms,
                 "points_per_launch": pts_per_launch, "launches": kl,
                 "kernel_share_of_step": st["query_kernel_ms"] / (dt * 1e3)}
     # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes of this same

@@ -13,7 +13,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-DOM = "k_query_packet<2, true>"
+DOM = "k_query_packet<2, true, true>"  # <Q_SDF, robust, approximate first pass>
 
 
 def short(n):
@@ -52,7 +52,7 @@ with open(os.path.join(dst, f"{tag}_pmc.txt"), "w") as fh:
 
 
 def per(counter):
-    k = [kk for kk in acc if kk[1] == counter and kk[0].startswith("k_query_packet<2, true>")]
+    k = [kk for kk in acc if kk[1] == counter and kk[0].startswith("k_query_packet<2, true")]
     return acc[k[0]] / len(disp[k[0]]) if k else None
 
 
