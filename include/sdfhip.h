@@ -222,7 +222,7 @@ int sdfhip_host_free(void* p);
  * scan instead of a tree walk; -1 = automatic (the default: ~5e8 x (vertices / 4000)^0.57), 0 = never), "heavy_budget" (chunks of four vertices a wave of the packet pass may evaluate before its queries go
  * to the one-wave-per-query kernel; 0 = automatic: 1/8 of the tree), "fast_nn" (0/1, applies at the next update: the vertex tree is built on the GPU, no host kd-tree;
  * distances stay exact, an exact fp32 distance tie goes to the lowest (Morton code, index) vertex instead of the
- * reference's first-visited one), "packet_group" (vertices per leaf group of the packet pass, 10..60, applies at the next update), "host_chunk" (points per
+ * reference's first-visited one), "packet_group" (vertices per leaf group of the packet pass, 10..60, 0 = automatic: 40 with the approximate first pass, else 24; applies at the next update), "host_chunk" (points per
  * staging slot of the host entry points, 0 = automatic),
  * "build_threads" (host threads of the kd-tree build; default min(cores, OMP_NUM_THREADS, 16)), "profile" (1: time every query kernel launch
  * with hipEvents on its stream, read back through sdfhip_get_stats; 2: same and reset). */

@@ -390,7 +390,9 @@ __device__ __forceinline__ ApproxLane kd_nearest_packet_approx(const MeshDev& M,
                     gm = fmin3(gm, a2, a3);
 #undef SDFK_APX_SLOT
                 }
-                // sorted insert of this group's minimum into B1..B4 (+ the groups of the first three)
+                // sorted insert of this group's minimum into B1..B4 (+ the groups of the first three);
+                // skipped when no lane's top four change (the insert is then the identity)
+                if (__ballot(gm < B4) != 0ull) {
                 const bool c1 = gm < B1, c2 = gm < B2, c3 = gm < B3;
                 H3 = c2 ? H2 : (c3 ? cur : H3);
                 H2 = c1 ? H1 : (c2 ? cur : H2);
@@ -402,6 +404,7 @@ __device__ __forceinline__ ApproxLane kd_nearest_packet_approx(const MeshDev& M,
                 t = fmaxf(B3, t2);
                 B3 = fminf(B3, t2);
                 B4 = fminf(B4, t);
+                }
             }
             need_pop = true;
         }

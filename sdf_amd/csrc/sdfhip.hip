@@ -167,6 +167,7 @@ struct sdfhip_ctx {
     int64_t opt_packet = 1;
     int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
     bool approx_ok = false;   // decided by every update(): see approx_pays()
+    int64_t opt_packet_group = 0;  // vertices per packet group: 0 automatic (40 with the approximate pass, else 24)
     float vmax2 = 0.f;        // max |v|^2 over the vertices, rounded up (strict mode)
     int64_t opt_build_threads = 1;
     uint32_t* d_adj_off = nullptr;
@@ -545,6 +546,13 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     // mesh AABB (sdf.cpp:36-37; == the kd root box): needed by the device side before the tree
     h->kd.bounds(h->h_verts, h->nv, (int)h->opt_build_threads, h->aabb);
     h->approx_ok = approx_pays(h);
+    // Packet groups: a slot of the approximate pass costs 3.5 VALU against 10 of the exact walk, so
+    // larger groups (fewer quad nodes, box tests and sorted inserts per wave) pay there.  Measured on
+    // the 424^2 torus, groups of 24 / 40 / 60: 64M random points sdf 16.8 / 16.3 / 16.9 ms, 256^3 grid
+    // nn 5.1 / 4.6 / 4.8 ms, 4M points nn 2.8 / 2.6 / 2.6 ms (the exact walk was tuned to 24).
+    h->kd.group_max = h->opt_packet_group > 0
+                          ? (uint32_t)h->opt_packet_group
+                          : ((h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0) ? 40u : 24u);
     if (h->robust && draw_R && !h->R_pinned) draw_rotation(h);
     // Device side (vertex upload, per-face precompute, LBVH order / refit) does not depend on
     // the kd-tree: it runs from a helper thread while this thread builds the tree.
@@ -1558,9 +1566,9 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_host_chunk = v;
     } else if (!strcmp(key, "packet_group")) {
         // vertices per packet group; takes effect at the next sdfhip_update
-        if (v < 10 || v > (int64_t)sdfk::KD_GROUP_LIMIT)
-            return fail(SDFHIP_E_INVALID, "packet_group must be in [10, %u]", sdfk::KD_GROUP_LIMIT);
-        h->kd.group_max = (uint32_t)v;
+        if (v != 0 && (v < 10 || v > (int64_t)sdfk::KD_GROUP_LIMIT))
+            return fail(SDFHIP_E_INVALID, "packet_group must be 0 (automatic) or in [10, %u]", sdfk::KD_GROUP_LIMIT);
+        h->opt_packet_group = v;
     } else if (!strcmp(key, "sort_min"))
         h->opt_sort_min = v;
     else if (!strcmp(key, "sort_min_contains"))
