@@ -682,9 +682,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_query_heavy(MeshDev M, const flo
                                                             int trunc_aabb, void* __restrict__ out,
                                                             uint32_t* __restrict__ fb_list,
                                                             uint32_t* __restrict__ fb_cnt, uint32_t cnt_all,
-                                                            int32_t* __restrict__ pos_out) {
+                                                            int32_t* __restrict__ pos_out, uint32_t only_min,
+                                                            uint32_t only_max) {
     __shared__ uint32_t sb[WAVES][HEAVY_Q], ss[WAVES][HEAVY_Q], sh[WAVES][HEAVY_Q];
     const uint32_t cnt = heavy_cnt ? *heavy_cnt : cnt_all;
+    // The length of the heavy list is known on the device only: the host launches a 16-wave and a
+    // 4-wave variant and each serves its own range of lengths (block-uniform exit, before any barrier).
+    if (cnt < only_min || cnt > only_max) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     constexpr uint32_t STEP = 64u * WAVES;  // positions per block per sub-step
     for (uint32_t q0 = HEAVY_Q * blockIdx.x; q0 < cnt; q0 += HEAVY_Q * gridDim.x) {  // block-uniform

@@ -822,10 +822,10 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         if (int rc = prof.begin()) return rc;
         if (packs <= 1024)  // few queries: 16 waves share each scan (the chain of one wave is ~0.4 ms at 190k)
             k_query_heavy<HK, ROBUST, 16><<<(uint32_t)packs, 1024, 0, s>>>(
-                M, d_pts, nullptr, nullptr, trunc, d_out, h->d_fb_list, h->d_fb_count, (uint32_t)n, pos);
+                M, d_pts, nullptr, nullptr, trunc, d_out, h->d_fb_list, h->d_fb_count, (uint32_t)n, pos, 0u, 0xFFFFFFFFu);
         else
             k_query_heavy<HK, ROBUST, 4><<<(uint32_t)(packs < 16384 ? packs : 16384), 256, 0, s>>>(
-                M, d_pts, nullptr, nullptr, trunc, d_out, h->d_fb_list, h->d_fb_count, (uint32_t)n, pos);
+                M, d_pts, nullptr, nullptr, trunc, d_out, h->d_fb_list, h->d_fb_count, (uint32_t)n, pos, 0u, 0xFFFFFFFFu);
         if (pos)
             k_scan_finish<HK, ROBUST><<<(uint32_t)((n + 255) / 256), 256, 0, s>>>(M, d_pts, pos, (uint32_t)n, trunc,
                                                                                  d_out);
@@ -858,9 +858,20 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             // queries of the waves that gave up (tail limiter): one wave per query; what is
             // still ambiguous afterwards joins the deferred list
             const int64_t packs = (deferred_pts + HEAVY_Q - 1) / HEAVY_Q;
-            k_query_heavy<HK, ROBUST, 4><<<(uint32_t)(packs < 8192 ? packs : 8192), 256, 0, s>>>(
+            // How many queries the list holds is known on the device only.  A short list (2k of 125M on
+            // the bench mesh) leaves the GPU empty with one 4-wave block per four queries, and one wave's
+            // chain over 190k positions is ~0.4 ms: 16 waves share each scan then (0.45 -> 0.3 ms).  A long
+            // one (41k of 64M on the smooth icosphere-7) is throughput bound and 4-wave blocks are faster
+            // (sdf 22.3 against 24.5 ms).  Both variants are launched; each returns at once outside its range.
+            constexpr uint32_t HEAVY_SHORT = 8192;
+            const int64_t g16 = packs < HEAVY_SHORT / HEAVY_Q ? packs : HEAVY_SHORT / HEAVY_Q;
+            k_query_heavy<HK, ROBUST, 16><<<(uint32_t)g16, 1024, 0, s>>>(
                 M, d_pts, h->d_fb_list + h->fb_cap, h->d_fb_count + 2, trunc, d_out, h->d_fb_list,
-                h->d_fb_count + flip, 0u, nullptr);
+                h->d_fb_count + flip, 0u, nullptr, 1u, HEAVY_SHORT);
+            if (deferred_pts > (int64_t)HEAVY_SHORT)
+                k_query_heavy<HK, ROBUST, 4><<<(uint32_t)(packs < 8192 ? packs : 8192), 256, 0, s>>>(
+                    M, d_pts, h->d_fb_list + h->fb_cap, h->d_fb_count + 2, trunc, d_out, h->d_fb_list,
+                    h->d_fb_count + flip, 0u, nullptr, HEAVY_SHORT + 1u, 0xFFFFFFFFu);
             HIPC(hipGetLastError());
         }
         if (!fast) {
