@@ -860,7 +860,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             const int64_t packs = (deferred_pts + HEAVY_Q - 1) / HEAVY_Q;
             // How many queries the list holds is known on the device only.  A short list (2k of 125M on
             // the bench mesh) leaves the GPU empty with one 4-wave block per four queries, and one wave's
-            // chain over 190k positions is ~0.4 ms: 16 waves share each scan then (0.45 -> 0.3 ms).  A long
+            // chain over 190k positions is ~0.4 ms: 16 waves share each scan then (0.45 -> 0.39 ms).  A long
             // one (41k of 64M on the smooth icosphere-7) is throughput bound and 4-wave blocks are faster
             // (sdf 22.3 against 24.5 ms).  Both variants are launched; each returns at once outside its range.
             constexpr uint32_t HEAVY_SHORT = 8192;
