@@ -182,6 +182,11 @@ struct KdHost {
     // zeros for n == 0.  Data-parallel for large n.
     void bounds(const float* pts, uint32_t n, int threads, float out[6]);
     void build_quads();
+    // The packet groups in position order (= nanoflann's DFS order, spatially coherent): refs
+    // KD_LEAF_BIT | (first pos / 4) << 4 | chunks.  The wide packet walk bounds each group, and
+    // each run of 64 consecutive groups, by an oriented box (kernels_build.h k_group_obb).
+    std::vector<uint32_t> groups;
+    void build_groups();
 
    private:
     struct Box {
@@ -824,6 +829,35 @@ inline uint32_t KdHost::quad_of(uint32_t ref, int level, uint32_t self, int& max
         }
     quads[self] = q;
     return self;
+}
+
+inline void KdHost::build_groups() {
+    groups.clear();
+    if (pos_vert.empty()) return;
+    // extents of every binary subtree (children follow their parent in pre-order: one reverse pass)
+    sub_first_.assign(nodes.size(), 0u);
+    sub_count_.assign(nodes.size(), 0u);
+    for (size_t i = nodes.size(); i-- > 0;) {
+        uint32_t f1, c1, f2, c2;
+        subtree_extent(nodes[i].ref1 & ~(3u << KD_FEAT_SHIFT), f1, c1);
+        subtree_extent(nodes[i].ref2, f2, c2);
+        sub_first_[i] = f1;
+        sub_count_[i] = c1 + c2;
+    }
+    // maximal subtrees with <= group_max vertices, left to right (explicit stack: child 2 below child 1)
+    std::vector<uint32_t> stack{root_ref & ~(3u << KD_FEAT_SHIFT)};
+    while (!stack.empty()) {
+        const uint32_t ref = stack.back();
+        stack.pop_back();
+        uint32_t first, count;
+        subtree_extent(ref, first, count);
+        if (count <= group_max) {
+            if (count) groups.push_back(KD_LEAF_BIT | ((first >> 2) << 4) | ((count + 3u) >> 2));
+            continue;
+        }
+        stack.push_back(nodes[ref].ref2);
+        stack.push_back(nodes[ref].ref1 & ~(3u << KD_FEAT_SHIFT));
+    }
 }
 
 inline void KdHost::build_quads() {

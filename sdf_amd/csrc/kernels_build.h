@@ -273,59 +273,211 @@ __global__ void k_fast_positions(const float* __restrict__ verts, const uint32_t
     }
 }
 constexpr uint32_t FAST_GROUP = 16;  // vertices per packet group (4 chunks)
-__device__ __forceinline__ void quad_store(float4* q, int k, const float* lo, const float* hi, uint32_t ref,
-                                           float* flat) {
-    (void)q;
-    for (int d = 0; d < 3; ++d) flat[6 * k + d] = lo[d], flat[6 * k + 3 + d] = hi[d];
-    flat[24 + k] = __uint_as_float(ref);
-    flat[28 + k] = 0.f;
+// fast_nn: the groups are the runs of FAST_GROUP consecutive positions
+__global__ void k_fast_grefs(uint32_t nv, uint32_t ngroups, uint32_t* __restrict__ grefs) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const uint32_t first = FAST_GROUP * g;
+    const uint32_t cnt = nv - first < FAST_GROUP ? nv - first : FAST_GROUP;
+    grefs[g] = KD_LEAF | ((first >> 2) << 4) | ((cnt + 3u) >> 2);
 }
-__global__ void k_fast_quads_leaf(const float4* __restrict__ pts4, uint32_t nv, uint32_t ngroups,
-                                  uint32_t nq, float4* __restrict__ out) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    float flat[32];
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t g = 4 * q + k;
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        uint32_t ref = KD_LEAF;  // unused slot: empty group (see kd_host.h quad_of)
-        if (g < ngroups) {
-            const uint32_t first = FAST_GROUP * g;
-            const uint32_t cnt = nv - first < FAST_GROUP ? nv - first : FAST_GROUP;
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const float4 p = pts4[first + j];
-                lo[0] = fminf(lo[0], p.x), lo[1] = fminf(lo[1], p.y), lo[2] = fminf(lo[2], p.z);
-                hi[0] = fmaxf(hi[0], p.x), hi[1] = fmaxf(hi[1], p.y), hi[2] = fmaxf(hi[2], p.z);
-            }
-            ref = KD_LEAF | ((first >> 2) << 4) | ((cnt + 3u) >> 2);
-        }
-        quad_store(nullptr, k, lo, hi, ref, flat);
+
+// =========================================================================================
+// Oriented boxes of the wide packet walk (kernels_packet.h).  A box record is 16 dwords
+//     { c.xyz, h0 | R0.xyz, h1 | R1.xyz, h2 | R2.xyz, tag }
+// (R_a: axes, rows; h_a: half extents; tag: the group's ref), stored per parent node as
+// [4][64] float4 so that lane k of the walk reads child k with unit stride.  The frame is the
+// PCA frame of the child's vertices (a surface patch is flat along its smallest axis); it only
+// has to be roughly orthonormal — what must hold exactly is  |R_a.(v - c)| <= h_a  for every
+// vertex v of the child and the STORED fp32 c, R_a: h_a is computed against those in double and
+// rounded up.  Anything non-finite gives the box that contains everything (h = +inf).
+// =========================================================================================
+__device__ __forceinline__ void obb_jacobi(double a00, double a01, double a02, double a11, double a12, double a22,
+                                           double V[3][3]) {
+    double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 8; ++sweep) {
+#define SDFK_JROT(P, Q)                                                                            \
+    if (fabs(A[P][Q]) > 1e-300) {                                                                  \
+        const double th = (A[Q][Q] - A[P][P]) / (2.0 * A[P][Q]);                                   \
+        const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));                \
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;                                       \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                            \
+            const double akp = A[k][P], akq = A[k][Q];                                             \
+            A[k][P] = c * akp - s * akq, A[k][Q] = s * akp + c * akq;                              \
+        }                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                            \
+            const double apk = A[P][k], aqk = A[Q][k];                                             \
+            A[P][k] = c * apk - s * aqk, A[Q][k] = s * apk + c * aqk;                              \
+        }                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                            \
+            const double vkp = V[k][P], vkq = V[k][Q];                                             \
+            V[k][P] = c * vkp - s * vkq, V[k][Q] = s * vkp + c * vkq;                              \
+        }                                                                                          \
     }
-    for (int j = 0; j < 8; ++j)
-        out[8 * (size_t)q + j] = make_float4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
+        SDFK_JROT(0, 1)
+        SDFK_JROT(0, 2)
+        SDFK_JROT(1, 2)
+#undef SDFK_JROT
+    }
 }
-__global__ void k_fast_quads_inner(const float4* __restrict__ child, uint32_t nchild, uint32_t child_off,
-                                   uint32_t nq, float4* __restrict__ out) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    float flat[32];
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t c = 4 * q + k;
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        uint32_t ref = KD_LEAF;
-        if (c < nchild) {
-            const float* cf = (const float*)(child + 8 * (size_t)c);
-            for (int j = 0; j < 4; ++j)
-                for (int d = 0; d < 3; ++d) {
-                    lo[d] = fminf(lo[d], cf[6 * j + d]);
-                    hi[d] = fmaxf(hi[d], cf[6 * j + 3 + d]);
-                }
-            ref = child_off + c;
-        }
-        quad_store(nullptr, k, lo, hi, ref, flat);
+struct ObbFrame {
+    float R[3][3];  // rows = axes (fp32, as stored)
+};
+__device__ __forceinline__ ObbFrame obb_frame(double n, const double s[3], const double ss[6]) {
+    // covariance from raw moments: ss = {xx, xy, xz, yy, yz, zz}
+    ObbFrame F;
+    const double inv = n > 0 ? 1.0 / n : 0.0;
+    const double mx = s[0] * inv, my = s[1] * inv, mz = s[2] * inv;
+    double V[3][3];
+    obb_jacobi(ss[0] * inv - mx * mx, ss[1] * inv - mx * my, ss[2] * inv - mx * mz, ss[3] * inv - my * my,
+               ss[4] * inv - my * mz, ss[5] * inv - mz * mz, V);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) F.R[a][d] = (float)V[d][a];
+    return F;
+}
+__device__ __forceinline__ void obb_store(float4* __restrict__ rec, uint32_t k, const ObbFrame& F, const double lo[3],
+                                          const double hi[3], const float c[3], const double hmax[3], uint32_t tag,
+                                          bool have_h) {
+    (void)lo, (void)hi;
+    float h[3];
+    bool ok = have_h;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        // rounded up with a margin: |R_a.(v - c)| <= h_a must hold for the fp32 record
+        h[a] = (float)(hmax[a] * (1.0 + 1e-6) + 1e-37);
+        h[a] = h[a] * (1.f + 1.2e-7f);
+        ok = ok && h[a] >= 0.f && h[a] < 3.0e38f && fabsf(c[a]) < 3.0e38f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ok = ok && fabsf(F.R[a][d]) <= 2.f;
     }
-    for (int j = 0; j < 8; ++j)
-        out[8 * (size_t)q + j] = make_float4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
+    if (ok) {
+        rec[k] = make_float4(c[0], c[1], c[2], h[0]);
+        rec[64u + k] = make_float4(F.R[0][0], F.R[0][1], F.R[0][2], h[1]);
+        rec[128u + k] = make_float4(F.R[1][0], F.R[1][1], F.R[1][2], h[2]);
+        rec[192u + k] = make_float4(F.R[2][0], F.R[2][1], F.R[2][2], __uint_as_float(tag));
+    } else {  // contains everything: always visited
+        const float inf = __builtin_inff();
+        rec[k] = make_float4(0.f, 0.f, 0.f, inf);
+        rec[64u + k] = make_float4(1.f, 0.f, 0.f, inf);
+        rec[128u + k] = make_float4(0.f, 1.f, 0.f, inf);
+        rec[192u + k] = make_float4(0.f, 0.f, 1.f, __uint_as_float(tag));
+    }
+}
+
+// one thread per packet group
+__global__ __launch_bounds__(64) void k_group_obb(const uint32_t* __restrict__ grefs, uint32_t ngroups,
+                                                  const float4* __restrict__ pts4, const int32_t* __restrict__ vind,
+                                                  float4* __restrict__ gobb) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const uint32_t ref = grefs[g];
+    const uint32_t first = ((ref & sdfk::KD_REF_MASK) >> 4) << 2, n4 = 4u * (ref & 15u);
+    double n = 0, s[3] = {0, 0, 0}, ss[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t k = first; k < first + n4; ++k) {
+        if (vind[k] < 0) continue;
+        const float4 P = pts4[k];
+        const double x = P.x, y = P.y, z = P.z;
+        n += 1.0, s[0] += x, s[1] += y, s[2] += z;
+        ss[0] += x * x, ss[1] += x * y, ss[2] += x * z, ss[3] += y * y, ss[4] += y * z, ss[5] += z * z;
+    }
+    const ObbFrame F = obb_frame(n, s, ss);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t k = first; k < first + n4; ++k) {
+        if (vind[k] < 0) continue;
+        const float4 P = pts4[k];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double pr = (double)F.R[a][0] * P.x + (double)F.R[a][1] * P.y + (double)F.R[a][2] * P.z;
+            lo[a] = fmin(lo[a], pr), hi[a] = fmax(hi[a], pr);
+        }
+    }
+    float c[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        c[d] = (float)(0.5 * ((lo[0] + hi[0]) * F.R[0][d] + (lo[1] + hi[1]) * F.R[1][d] + (lo[2] + hi[2]) * F.R[2][d]));
+    double hmax[3] = {0, 0, 0};
+    for (uint32_t k = first; k < first + n4; ++k) {
+        if (vind[k] < 0) continue;
+        const float4 P = pts4[k];
+        const double x = (double)P.x - c[0], y = (double)P.y - c[1], z = (double)P.z - c[2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            hmax[a] = fmax(hmax[a], fabs((double)F.R[a][0] * x + (double)F.R[a][1] * y + (double)F.R[a][2] * z));
+    }
+    obb_store(gobb + 256u * (size_t)(g >> 6), g & 63u, F, lo, hi, c, hmax, ref, n > 0);
+}
+
+// one wave per L1 node (run of 64 consecutive groups): lane k handles the vertices of group k
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_min_d(double v) {
+    for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__global__ __launch_bounds__(64) void k_l1_obb(const uint32_t* __restrict__ grefs, uint32_t ngroups,
+                                               const float4* __restrict__ pts4, const int32_t* __restrict__ vind,
+                                               float4* __restrict__ l1obb) {
+    const uint32_t j = blockIdx.x, lane = threadIdx.x;
+    const uint32_t g = 64u * j + lane;
+    uint32_t first = 0, n4 = 0;
+    if (g < ngroups) {
+        const uint32_t ref = grefs[g];
+        first = ((ref & sdfk::KD_REF_MASK) >> 4) << 2, n4 = 4u * (ref & 15u);
+    }
+    double n = 0, s[3] = {0, 0, 0}, ss[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t k = first; k < first + n4; ++k) {
+        if (vind[k] < 0) continue;
+        const float4 P = pts4[k];
+        const double x = P.x, y = P.y, z = P.z;
+        n += 1.0, s[0] += x, s[1] += y, s[2] += z;
+        ss[0] += x * x, ss[1] += x * y, ss[2] += x * z, ss[3] += y * y, ss[4] += y * z, ss[5] += z * z;
+    }
+    n = wave_sum_d(n);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) s[d] = wave_sum_d(s[d]);
+#pragma unroll
+    for (int d = 0; d < 6; ++d) ss[d] = wave_sum_d(ss[d]);
+    const ObbFrame F = obb_frame(n, s, ss);  // every lane, identically
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t k = first; k < first + n4; ++k) {
+        if (vind[k] < 0) continue;
+        const float4 P = pts4[k];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double pr = (double)F.R[a][0] * P.x + (double)F.R[a][1] * P.y + (double)F.R[a][2] * P.z;
+            lo[a] = fmin(lo[a], pr), hi[a] = fmax(hi[a], pr);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) lo[a] = wave_min_d(lo[a]), hi[a] = wave_max_d(hi[a]);
+    float c[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        c[d] = (float)(0.5 * ((lo[0] + hi[0]) * F.R[0][d] + (lo[1] + hi[1]) * F.R[1][d] + (lo[2] + hi[2]) * F.R[2][d]));
+    double hmax[3] = {0, 0, 0};
+    for (uint32_t k = first; k < first + n4; ++k) {
+        if (vind[k] < 0) continue;
+        const float4 P = pts4[k];
+        const double x = (double)P.x - c[0], y = (double)P.y - c[1], z = (double)P.z - c[2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            hmax[a] = fmax(hmax[a], fabs((double)F.R[a][0] * x + (double)F.R[a][1] * y + (double)F.R[a][2] * z));
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) hmax[a] = wave_max_d(hmax[a]);
+    if (lane == 0) obb_store(l1obb + 256u * (size_t)(j >> 6), j & 63u, F, lo, hi, c, hmax, j, n > 0);
 }
 
 // column grid build: count (or fill) the cells each face's rotated AABB touches

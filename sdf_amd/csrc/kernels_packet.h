@@ -29,14 +29,27 @@
 // the query is "ambiguous" and is appended to a fallback list that the strict per-lane
 // kernel (kd_nearest: exact emulation) processes afterwards.  Parity is by construction.
 // =========================================================================================
+#ifndef SDFK_CHUNK_BATCH
+#define SDFK_CHUNK_BATCH 3
+#endif
+#ifndef SDFK_EXP
+#define SDFK_EXP 0
+#endif
 #ifndef SDFK_PBLOCK
 #define SDFK_PBLOCK 64
 #endif
 constexpr int PBLOCK = SDFK_PBLOCK;
 // 80 SGPRs or fewer admit 8 waves per SIMD, 82-96 only 7 (MI355X_MICROARCH.md "Residency"); the
 // compiler would take 90.  Measured: robust sdf kernel 16.3 -> 15.5 ms for 64M points, nn unchanged.
+#ifndef SDFK_PK_NSGPR
+#define SDFK_PK_NSGPR 96
+#endif
 #ifndef SDFK_PK_SGPR
-#define SDFK_PK_SGPR __attribute__((amdgpu_num_sgpr(80)))
+#ifdef SDFK_PK_NVGPR
+#define SDFK_PK_SGPR __attribute__((amdgpu_num_sgpr(SDFK_PK_NSGPR), amdgpu_num_vgpr(SDFK_PK_NVGPR)))
+#else
+#define SDFK_PK_SGPR __attribute__((amdgpu_num_sgpr(SDFK_PK_NSGPR)))
+#endif
 #endif
 
 
@@ -104,181 +117,246 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 // One chunk = four padded vertices = 64 B = one s_load_dwordx16.
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
-// Deferred children of the wave live on a stack in LDS.  Per level: the uniform child ref and,
-// per lane, the upper 16 bits of that lane's box lower bound (truncation keeps it a lower
-// bound), so that a pop is one LDS read and a compare against the lane's current threshold —
-// no node reload, no box arithmetic.
-struct PacketStack {
-    uint16_t* lb;   // [level][64]
-    uint32_t* ref;  // [level]
-};
-
 #ifdef SDFK_STATS
 // tuning build only (make stats): per-wave work counters of the packet pass
-__device__ unsigned long long g_pk_stats[8];  // waves, quad nodes, groups, chunks, tie redos, pops, pushes
+__device__ unsigned long long g_pk_stats[8];  // waves, wide tests, groups, chunks, tie redos, candidates, near ties, deferred
 #define SDFK_COUNT(K, V) if ((threadIdx.x & 63) == 0) atomicAdd(&g_pk_stats[K], (unsigned long long)(V))
 #else
 #define SDFK_COUNT(K, V)
 #endif
 
-__device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float qx, float qy, float qz,
-                                                        const PacketStack stk) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t b = 0x7F7FFFFFu, s2 = 0x7F7FFFFFu;  // FLT_MAX bits (KNNResultSet::init)
-    uint32_t h = H_NONE;
-    // A lane whose minimum is an exact tie that has been settled keeps s2 = b + 1 (so that one
-    // more vertex at that distance shows up again as s2 == b) and remembers the tied value here.
-    uint32_t tieb = 0xFFFFFFFFu;
-    const float c = M.amb_c2;  // everything within best * c^2 is evaluated
-    uint32_t cur = M.kd_qroot;
-    uint32_t sp = 0;
-    uint32_t work = 0;  // chunks evaluated so far (wave-uniform)
-    SDFK_COUNT(0, 1);
-    for (;;) {
-        cur = __builtin_amdgcn_readfirstlane(cur);
-        bool need_pop = false;
-        if (!(cur & KD_LEAF)) {
-            SDFK_COUNT(1, 1);
-            // 4-wide node: boxes and child refs by scalar loads; slots 0,1 / 2,3 are the two
-            // binary sides
-            const float* Q = (const float*)(M.kd_qn + 8 * (size_t)cur);
-            const uint32_t r0 = __float_as_uint(Q[24]), r1 = __float_as_uint(Q[25]),
-                           r2 = __float_as_uint(Q[26]), r3 = __float_as_uint(Q[27]);
-            const float thr = __uint_as_float(b) * c;
-            const float lb0 = box_lb(qx, qy, qz, Q[0], Q[1], Q[2], Q[3], Q[4], Q[5]);
-            const float lb1 = box_lb(qx, qy, qz, Q[6], Q[7], Q[8], Q[9], Q[10], Q[11]);
-            const float lb2 = box_lb(qx, qy, qz, Q[12], Q[13], Q[14], Q[15], Q[16], Q[17]);
-            const float lb3 = box_lb(qx, qy, qz, Q[18], Q[19], Q[20], Q[21], Q[22], Q[23]);
-            const uint32_t act = (__ballot(lb0 <= thr) != 0ull ? 1u : 0u) |
-                                 (__ballot(lb1 <= thr) != 0ull ? 2u : 0u) |
-                                 (__ballot(lb2 <= thr) != 0ull ? 4u : 0u) |
-                                 (__ballot(lb3 <= thr) != 0ull ? 8u : 0u);
-            if (act == 0u) {
-                need_pop = true;
-            } else if ((act & (act - 1u)) == 0u) {
-                cur = act == 1u ? r0 : (act == 2u ? r1 : (act == 4u ? r2 : r3));
-            } else {
-                // visiting order by box distance, majority vote per comparison (any order is
-                // exact; nearer first tightens `b` sooner).  Every active child is pushed,
-                // farthest first, then the nearest is taken straight back.
-                const uint32_t u0 = __float_as_uint(lb0), u1 = __float_as_uint(lb1),
-                               u2 = __float_as_uint(lb2), u3 = __float_as_uint(lb3);
-                const bool a_first = (int)__popcll(__ballot(min(u0, u1) <= min(u2, u3))) >= 32;
-                const bool s01 = (int)__popcll(__ballot(u0 <= u1)) >= 32;
-                const bool s23 = (int)__popcll(__ballot(u2 <= u3)) >= 32;
-                uint32_t last = 0;
-#define SDFK_PK_PUSH(K)                                              \
-    if (act & (1u << K)) {                                           \
-        stk.lb[sp * 64u + lane] = (uint16_t)(u##K >> 16);            \
-        stk.ref[sp] = r##K;                                          \
-        last = r##K;                                                 \
-        ++sp;                                                        \
+// ---- wave-wide reductions by DPP (all 64 lanes active, wave-uniform control flow) ----------------
+#define SDFK_DPP(IDENT, V, CTRL, RMASK) \
+    ((uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)(V), (CTRL), (RMASK), 0xf, false))
+// row_shr:1,2,4,8 fold each row of 16 into its last lane, row_bcast:15 / :31 fold the rows into lane 63
+#define SDFK_WAVE_REDUCE(V, IDENT, OP)                          \
+    V = OP(V, SDFK_DPP(IDENT, V, 0x111, 0xf));                  \
+    V = OP(V, SDFK_DPP(IDENT, V, 0x112, 0xf));                  \
+    V = OP(V, SDFK_DPP(IDENT, V, 0x114, 0xf));                  \
+    V = OP(V, SDFK_DPP(IDENT, V, 0x118, 0xf));                  \
+    V = OP(V, SDFK_DPP(IDENT, V, 0x142, 0xa));                  \
+    V = OP(V, SDFK_DPP(IDENT, V, 0x143, 0xc));
+__device__ __forceinline__ uint32_t umax2(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umin2(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+    SDFK_WAVE_REDUCE(v, 0u, umax2)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
+    SDFK_WAVE_REDUCE(v, 0xFFFFFFFFu, umin2)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// order-preserving map of finite / infinite floats onto unsigned integers (NaN sorts past +inf)
+__device__ __forceinline__ uint32_t pk_f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float pk_ord2f(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+__device__ __forceinline__ float wave_readf(float v, uint32_t l) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), (int)l));
+}
+
+// =========================================================================================
+// Wide packet walk.  The vertices' packet groups (maximal kd subtrees of <= group_max vertices, in
+// position order) are bounded by ORIENTED boxes: the vertices lie on a surface, a patch of it is
+// nearly flat, and an oriented box follows the patch where an axis-aligned one is as thick as the
+// patch is wide (measured with tools/obb_probe.cpp on the 424^2 torus: 2.6x fewer vertex slots per
+// wave than the 4-wide tree of axis-aligned boxes this replaces).  Two levels, 64 children each:
+// an L1 node is a run of 64 consecutive groups.  A node is tested against the PACKET by all lanes
+// at once — lane k tests child k against the sphere around the wave's 64 queries — so a level
+// costs ~40 VALU per wave where a per-lane box test of 4 children cost 56 per quad node; the
+// children of the packet's candidates stay in the lanes' registers.
+//
+// Pruning is conservative at every step (a vertex v of child box B, query q_l of lane l, packet
+// centre c, radius rho >= |q_l - c|, thresholds thr_l >= everything lane l must still see):
+//   packet level   dist(c, B) > max_l sqrt(thr_l) + rho            =>  |q_l - v| > sqrt(thr_l) for all l
+//   lane level     f0 + n.(q_l - c) > sqrt(thr_l)  for every lane  =>  the same, where the half space
+//                  {x : n.(x - c) <= -f0}, |n| <= 1, contains B (n = direction from B to c, f0 from
+//                  the support function of B): a plane bound that is nearly as sharp as the exact
+//                  per-lane box distance (obb_probe: 8.1 against 7.4 groups per wave) for 4 readlanes
+//                  and 3 FMAs per candidate.
+// Rounding: box records are fp32; the half extents are computed against the STORED centre and axes
+// and rounded up (k_group_obb), the projections' absolute error (<= 8u |c - c_B|) is covered by Ew
+// (64u x an upper bound of |c - c_B|), the relative ones by EPS = 2^-18 on the thresholds.  Every
+// prune is of the form "x > y is true", so a NaN anywhere means "visit".
+// What is exact is unchanged: every evaluated group runs the reference's arithmetic, and the walk
+// ends with the same (b, s, h) / (B1..B4, H1..H3) as the tree walk it replaces.
+// =========================================================================================
+constexpr float PK_EPS = 3.8146973e-6f;  // 2^-18
+struct ObbLane {
+    float dP;                 // squared distance from the packet centre to this lane's child box (lower bound)
+    float nx, ny, nz, f0;     // half space containing the box: n.(x - c) <= -f0
+    float pk;                 // f0 - |n - g| rho: packet-level bound against the thresholds' linear trend g
+    uint32_t tag;             // group ref (group level)
+};
+// lane `lane` tests child `lane` of one node (rec: [4][64] float4, see k_group_obb) against c
+template <bool PLANE>
+__device__ __forceinline__ ObbLane obb_wide(const float4* __restrict__ rec, uint32_t lane, float cx, float cy,
+                                            float cz, float Ew, float gx = 0.f, float gy = 0.f, float gz = 0.f,
+                                            float rho = 0.f) {
+    const float4 A = rec[lane], B = rec[64u + lane], C = rec[128u + lane], D = rec[192u + lane];
+    const float dx = cx - A.x, dy = cy - A.y, dz = cz - A.z;
+    const float p0 = __builtin_fmaf(B.x, dx, __builtin_fmaf(B.y, dy, B.z * dz));
+    const float p1 = __builtin_fmaf(C.x, dx, __builtin_fmaf(C.y, dy, C.z * dz));
+    const float p2 = __builtin_fmaf(D.x, dx, __builtin_fmaf(D.y, dy, D.z * dz));
+    const float g0 = fmaxf(fabsf(p0) - (A.w + Ew), 0.f);
+    const float g1 = fmaxf(fabsf(p1) - (B.w + Ew), 0.f);
+    const float g2 = fmaxf(fabsf(p2) - (C.w + Ew), 0.f);
+    ObbLane o;
+    o.dP = __builtin_fmaf(g0, g0, __builtin_fmaf(g1, g1, g2 * g2));
+    o.tag = __float_as_uint(D.w);
+    o.nx = o.ny = o.nz = o.f0 = o.pk = 0.f;
+    if (PLANE) {
+        // n = sum_a sign(p_a) g_a R_a / |g|, scaled down so that |n| <= 1 whatever the rounding
+        const float inv = o.dP > 0.f ? __builtin_amdgcn_rsqf(o.dP) * (1.f - PK_EPS) : 0.f;
+        const float s0 = copysignf(g0, p0) * inv, s1 = copysignf(g1, p1) * inv, s2 = copysignf(g2, p2) * inv;
+        o.nx = __builtin_fmaf(s0, B.x, __builtin_fmaf(s1, C.x, s2 * D.x));
+        o.ny = __builtin_fmaf(s0, B.y, __builtin_fmaf(s1, C.y, s2 * D.y));
+        o.nz = __builtin_fmaf(s0, B.z, __builtin_fmaf(s1, C.z, s2 * D.z));
+        // f0 = n.(c - c_B) - max_{x in B} n.(x - c_B) = n.(c - c_B) - sum_a h_a |n.R_a|
+        const float m0 = __builtin_fmaf(o.nx, B.x, __builtin_fmaf(o.ny, B.y, o.nz * B.z));
+        const float m1 = __builtin_fmaf(o.nx, C.x, __builtin_fmaf(o.ny, C.y, o.nz * C.z));
+        const float m2 = __builtin_fmaf(o.nx, D.x, __builtin_fmaf(o.ny, D.y, o.nz * D.z));
+        const float sup = __builtin_fmaf(A.w, fabsf(m0), __builtin_fmaf(B.w, fabsf(m1), C.w * fabsf(m2)));
+        o.f0 = __builtin_fmaf(o.nx, dx, __builtin_fmaf(o.ny, dy, o.nz * dz)) - (sup + 4.f * Ew);
+        // for every lane l:  f0 + n.e_l - rr_l  =  f0 + (n - g).e_l - (rr_l - g.e_l)  >=  pk - max_l (rr_l - g.e_l)
+        const float ux = o.nx - gx, uy = o.ny - gy, uz = o.nz - gz;
+        const float dn = __builtin_amdgcn_sqrtf(__builtin_fmaf(ux, ux, __builtin_fmaf(uy, uy, uz * uz)));
+        o.pk = o.f0 - __builtin_fmaf(dn, 1.f + PK_EPS, PK_EPS) * rho;
     }
-#define SDFK_PK_ORDER(A, B, C, D) { SDFK_PK_PUSH(D) SDFK_PK_PUSH(C) SDFK_PK_PUSH(B) SDFK_PK_PUSH(A) }
-                if (a_first) {
-                    if (s01) {
-                        if (s23) SDFK_PK_ORDER(0, 1, 2, 3) else SDFK_PK_ORDER(0, 1, 3, 2)
-                    } else {
-                        if (s23) SDFK_PK_ORDER(1, 0, 2, 3) else SDFK_PK_ORDER(1, 0, 3, 2)
-                    }
-                } else {
-                    if (s01) {
-                        if (s23) SDFK_PK_ORDER(2, 3, 0, 1) else SDFK_PK_ORDER(3, 2, 0, 1)
-                    } else {
-                        if (s23) SDFK_PK_ORDER(2, 3, 1, 0) else SDFK_PK_ORDER(3, 2, 1, 0)
-                    }
-                }
-#undef SDFK_PK_ORDER
-#undef SDFK_PK_PUSH
-                --sp;
-                cur = last;
-            }
-        } else {
-            // packet group: chunks of four slots, 64 B each by one scalar load
-            const uint32_t nch = cur & 15u;
-            const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
-            const float4* P = M.kd_pts4 + first;
-            const uint32_t b0 = b, s0 = s2, h0 = h;
-            // Tail limiter.  A wave whose queries sit near a centre of symmetry of the mesh (the
-            // middle of a sphere) needs most of the tree, one dependent scalar load after the
-            // other: ~0.3 us per chunk, 12 ms for 180k vertices, and the launch cannot end before
-            // it does.  Past the budget the wave hands its queries to k_query_heavy (one wave
-            // per query, lanes over the vertices).
-            work += nch;
-            SDFK_COUNT(2, 1);
-            SDFK_COUNT(3, nch);
-            if (nch) {
-                const u32x16* C = (const u32x16*)__builtin_assume_aligned(P, 64);
-#ifdef SDFK_PREFETCH
-                // one chunk ahead: the load of chunk ci + 1 is in flight while chunk ci is evaluated
-                u32x16 A = C[0];
-                for (uint32_t ci = 0; ci < nch; ++ci) {
-                    const u32x16 N = C[ci + 1 < nch ? ci + 1 : ci];
-                    SDFK_PACKET_CHUNK(A)
-                    A = N;
-                }
-#else
-                for (uint32_t ci = 0; ci < nch; ++ci) {
-                    const u32x16 A = C[ci];
-                    SDFK_PACKET_CHUNK(A)
-                }
+    return o;
+}
+// sort key of a box distance: its bit pattern (non-negative floats order like integers); NaN -> 0 (nearest)
+__device__ __forceinline__ uint32_t obb_key(float dP, bool valid) {
+    return valid ? (dP == dP ? __float_as_uint(dP) : 0u) : 0xFFFFFFFFu;
+}
+
+// per-lane state of the two flavours of the pass (what a group evaluation updates)
+struct ExactState {
+    uint32_t b, s2, h, tieb;  // see PacketBest; tieb: value of a settled exact tie (s2 is kept at b + 1)
+};
+struct ApproxState {
+    float B1, B2, B3, B4;
+    uint32_t H1, H2, H3;
+};
+
+// exact evaluation of group `cur` for the wave (reference arithmetic, 10 VALU per slot)
+__device__ __forceinline__ void group_exact(const MeshDev& M, float qx, float qy, float qz, uint32_t cur,
+                                            ExactState& S) {
+    const uint32_t nch = cur & 15u;
+    const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
+    const float4* P = M.kd_pts4 + first;
+    uint32_t b = S.b, s2 = S.s2, h = S.h;
+    const uint32_t b0 = b, s0 = s2, h0 = h;
+    const u32x16* C = (const u32x16*)__builtin_assume_aligned(P, 64);
+    uint32_t ci = 0;
+#if SDFK_CHUNK_BATCH >= 3
+    for (; ci + 3u <= nch; ci += 3u) {
+        const u32x16 A0 = C[ci], A1 = C[ci + 1u], A2 = C[ci + 2u];
+        SDFK_PACKET_CHUNK(A0) SDFK_PACKET_CHUNK(A1) SDFK_PACKET_CHUNK(A2)
+    }
 #endif
-                if (b != b0) h = cur;  // strictly improved here: the holder is in this group
-                if (__ballot(s2 == b) != 0ull) {
-                    // rare: some lane's two smallest distances are equal.  Redo the group for
-                    // the wave in ascending position and settle each exact tie by DFS order.
-                    b = b0, s2 = s0, h = h0;
-                    SDFK_COUNT(4, 1);
-                    for (uint32_t k = 0; k < 4u * nch; ++k) {
-                        const float4 Qp = P[k];
-                        const float dx = qx - Qp.x, dy = qy - Qp.y, dz = qz - Qp.z;
-                        const uint32_t du = __float_as_uint((dx * dx + dy * dy) + dz * dz);
-                        const uint32_t idx = first + k;
-                        if (du == b && h != H_NONE) {
-                            // any position of the holder's group stands for the holder: the
-                            // two part above that group
-                            const uint32_t hp = (h & KD_LEAF) ? (((h & sdfk::KD_REF_MASK) >> 4) << 2) : h;
-                            // (a group ref in h always names an earlier group: h0 predates this one)
-                            const bool idx_first =
-                                M.fast ? idx < hp : (uint32_t)kd_dfs_first(M, qx, qy, qz, (int)hp, (int)idx) == idx;
-                            if (idx_first) h = idx;
-                        }
-                        s2 = min(s2, max(du, b));
-                        if (du < b) {
-                            b = du;
-                            h = idx;
-                        }
-                    }
-                    if (s2 == b) tieb = b, s2 = b + 1u;
-                }
+#if SDFK_CHUNK_BATCH >= 2
+    for (; ci + 2u <= nch; ci += 2u) {
+        const u32x16 A0 = C[ci], A1 = C[ci + 1u];
+        SDFK_PACKET_CHUNK(A0) SDFK_PACKET_CHUNK(A1)
+    }
+#endif
+    for (; ci < nch; ++ci) {
+        const u32x16 A0 = C[ci];
+        SDFK_PACKET_CHUNK(A0)
+    }
+    if (b != b0) h = cur;  // strictly improved here: the holder is in this group
+    if (__ballot(s2 == b) != 0ull) {
+        // rare: some lane's two smallest distances are equal.  Redo the group for the wave in
+        // ascending position and settle each exact tie by DFS order.
+        b = b0, s2 = s0, h = h0;
+        SDFK_COUNT(4, 1);
+        for (uint32_t k = 0; k < 4u * nch; ++k) {
+            const float4 Qp = P[k];
+            const float dx = qx - Qp.x, dy = qy - Qp.y, dz = qz - Qp.z;
+            const uint32_t du = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+            const uint32_t idx = first + k;
+            if (du == b && h != H_NONE) {
+                // any position of the holder's group stands for the holder: the two part above that group
+                const uint32_t hp = (h & KD_LEAF) ? (((h & sdfk::KD_REF_MASK) >> 4) << 2) : h;
+                // (a group ref in h always names an earlier group: h0 predates this one)
+                const bool idx_first =
+                    M.fast ? idx < hp : (uint32_t)kd_dfs_first(M, qx, qy, qz, (int)hp, (int)idx) == idx;
+                if (idx_first) h = idx;
             }
-            need_pop = true;
-        }
-        if (need_pop) {
-            const uint32_t thr16 = __float_as_uint(__uint_as_float(b) * c) >> 16;
-            const bool over = work > M.heavy_budget;  // give up: drop what is still on the stack
-            if (over) sp = 0;
-            for (;;) {
-                if (sp == 0) {
-                    if (b == tieb) s2 = b;
-                    return PacketBest{__uint_as_float(b), __uint_as_float(s2), over, h};
-                }
-                --sp;
-                SDFK_COUNT(5, 1);
-                const uint32_t l16 = stk.lb[sp * 64u + lane];
-                const uint32_t r = stk.ref[sp];
-                if (__ballot(l16 <= thr16) != 0ull) {
-                    cur = r;
-                    break;
-                }
+            s2 = min(s2, max(du, b));
+            if (du < b) {
+                b = du;
+                h = idx;
             }
         }
+        if (s2 == b) S.tieb = b, s2 = b + 1u;
+    }
+    S.b = b, S.s2 = s2, S.h = h;
+}
+
+// approximate evaluation (see "Approximate first pass" below): group minimum of a(), sorted insert
+__device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y2, float Z2, uint32_t cur,
+                                             ApproxState& S) {
+    const uint32_t nch = cur & 15u;
+    const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
+    const u32x16* C = (const u32x16*)__builtin_assume_aligned(M.kd_pts4 + first, 64);
+    float gm = __builtin_inff();  // (a NaN never enters: fminf keeps the other operand)
+#define SDFK_APX_SLOT(A, O_)                                                               \
+    __builtin_fmaf(X2, __uint_as_float(A[O_]),                                             \
+                   __builtin_fmaf(Y2, __uint_as_float(A[O_ + 1]),                          \
+                                  __builtin_fmaf(Z2, __uint_as_float(A[O_ + 2]), __uint_as_float(A[O_ + 3]))))
+    // 12 FMA + 2 v_min3 per chunk (a NaN operand is dropped by min3 as by min)
+#define SDFK_APX_CHUNK(A)                                                                                  \
+    {                                                                                                      \
+        const float a0 = SDFK_APX_SLOT(A, 0), a1 = SDFK_APX_SLOT(A, 4), a2 = SDFK_APX_SLOT(A, 8),          \
+                    a3 = SDFK_APX_SLOT(A, 12);                                                             \
+        gm = fmin3(gm, a0, a1);                                                                            \
+        gm = fmin3(gm, a2, a3);                                                                            \
+    }
+    // The walk is a chain of dependent loads: the chunk loads of a group go out SDFK_CHUNK_BATCH at a time
+    uint32_t ci = 0;
+#if SDFK_CHUNK_BATCH >= 3
+    for (; ci + 3u <= nch; ci += 3u) {
+        const u32x16 A0 = C[ci], A1 = C[ci + 1u], A2 = C[ci + 2u];
+        SDFK_APX_CHUNK(A0) SDFK_APX_CHUNK(A1) SDFK_APX_CHUNK(A2)
+    }
+#endif
+#if SDFK_CHUNK_BATCH >= 2
+    for (; ci + 2u <= nch; ci += 2u) {
+        const u32x16 A0 = C[ci], A1 = C[ci + 1u];
+        SDFK_APX_CHUNK(A0) SDFK_APX_CHUNK(A1)
+    }
+#endif
+    for (; ci < nch; ++ci) {
+        const u32x16 A0 = C[ci];
+        SDFK_APX_CHUNK(A0)
+    }
+#undef SDFK_APX_CHUNK
+#undef SDFK_APX_SLOT
+    // sorted insert of this group's minimum into B1..B4 (+ the groups of the first three);
+    // skipped when no lane's top four change (the insert is then the identity)
+    if (__ballot(gm < S.B4) != 0ull) {
+        const bool c1 = gm < S.B1, c2 = gm < S.B2, c3 = gm < S.B3;
+        S.H3 = c2 ? S.H2 : (c3 ? cur : S.H3);
+        S.H2 = c1 ? S.H1 : (c2 ? cur : S.H2);
+        S.H1 = c1 ? cur : S.H1;
+        float t = fmaxf(S.B1, gm);
+        S.B1 = fminf(S.B1, gm);
+        float t2 = fmaxf(S.B2, t);
+        S.B2 = fminf(S.B2, t);
+        t = fmaxf(S.B3, t2);
+        S.B3 = fminf(S.B3, t2);
+        S.B4 = fminf(S.B4, t);
     }
 }
 
 // =========================================================================================
-// Approximate first pass (strict mode).  The walk above spends 10 VALU per (query, vertex) on the
-// reference's exact arithmetic although almost every vertex it meets is NOT the nearest one.
+// Approximate first pass (strict mode).  The exact evaluation spends 10 VALU per (query, vertex) on the
+// reference's arithmetic although almost every vertex it meets is NOT the nearest one.
 // Here a slot costs 4: with the vertex's squared norm in the padding word of kd_pts4,
 //     a(v) = fma(-2qx, vx, fma(-2qy, vy, fma(-2qz, vz, |v|^2)))  ~  D(v) - |q|^2
 // orders the vertices of one lane like nanoflann's fp32 distance D(v) up to a known error: with
@@ -297,134 +375,148 @@ __device__ __forceinline__ PacketBest kd_nearest_packet(const MeshDev& M, float 
 // lower(B_next) is a lower bound of the distance of every outside vertex — which is all the
 // decision logic needs of `s`.  A fourth candidate group defers the query to the strict kernel.
 // =========================================================================================
-struct ApproxLane {
-    float B1, B2, B3, B4;  // smallest group minima of a(), ascending
-    uint32_t H1, H2, H3;   // refs of the groups of B1..B3 (H_NONE: none)
-    bool bailed;
-};
 
-__device__ __forceinline__ ApproxLane kd_nearest_packet_approx(const MeshDev& M, float qx, float qy, float qz,
-                                                               float Qe, float cm, const PacketStack stk) {
+// The walk itself.  APPROX: SA is updated (thresholds from upper(B1) * c^2 = max(B1 + Qe, 0) * cm),
+// else SE (thresholds b * c^2).  Returns true when the wave gave up (work budget, see k_query_heavy).
+template <bool APPROX>
+__device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy, float qz, float Qe, float cm,
+                                            ExactState& SE, ApproxState& SA) {
     const uint32_t lane = threadIdx.x & 63u;
-    const float INF = __builtin_inff();
-    const float X2 = -2.f * qx, Y2 = -2.f * qy, Z2 = -2.f * qz;
-    float B1 = INF, B2 = INF, B3 = INF, B4 = INF;
-    uint32_t H1 = H_NONE, H2 = H_NONE, H3 = H_NONE;
-    uint32_t cur = M.kd_qroot;
-    uint32_t sp = 0;
-    uint32_t work = 0;
     SDFK_COUNT(0, 1);
-    for (;;) {
-        cur = __builtin_amdgcn_readfirstlane(cur);
-        bool need_pop = false;
-        if (!(cur & KD_LEAF)) {
-            SDFK_COUNT(1, 1);
-            const float* Q = (const float*)(M.kd_qn + 8 * (size_t)cur);
-            const uint32_t r0 = __float_as_uint(Q[24]), r1 = __float_as_uint(Q[25]),
-                           r2 = __float_as_uint(Q[26]), r3 = __float_as_uint(Q[27]);
-            const float thr = fmaxf(B1 + Qe, 0.f) * cm;  // >= (exact best so far) * c^2
-            const float lb0 = box_lb(qx, qy, qz, Q[0], Q[1], Q[2], Q[3], Q[4], Q[5]);
-            const float lb1 = box_lb(qx, qy, qz, Q[6], Q[7], Q[8], Q[9], Q[10], Q[11]);
-            const float lb2 = box_lb(qx, qy, qz, Q[12], Q[13], Q[14], Q[15], Q[16], Q[17]);
-            const float lb3 = box_lb(qx, qy, qz, Q[18], Q[19], Q[20], Q[21], Q[22], Q[23]);
-            const uint32_t act = (__ballot(lb0 <= thr) != 0ull ? 1u : 0u) |
-                                 (__ballot(lb1 <= thr) != 0ull ? 2u : 0u) |
-                                 (__ballot(lb2 <= thr) != 0ull ? 4u : 0u) |
-                                 (__ballot(lb3 <= thr) != 0ull ? 8u : 0u);
-            if (act == 0u) {
-                need_pop = true;
-            } else if ((act & (act - 1u)) == 0u) {
-                cur = act == 1u ? r0 : (act == 2u ? r1 : (act == 4u ? r2 : r3));
+    if (M.kd_ngroups == 0u) return false;
+#if SDFK_EXP == 3
+    return false;
+#endif
+    // sphere around the wave's queries: centre of their bounding box, radius = farthest query
+    const float cx = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(qx))) + pk_ord2f(wave_umax(pk_f2ord(qx))));
+    const float cy = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(qy))) + pk_ord2f(wave_umax(pk_f2ord(qy))));
+    const float cz = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(qz))) + pk_ord2f(wave_umax(pk_f2ord(qz))));
+    const float ex = qx - cx, ey = qy - cy, ez = qz - cz;
+    const float e2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
+    const float rho = __builtin_amdgcn_sqrtf(__uint_as_float(wave_umax(__float_as_uint(e2)))) * (1.f + PK_EPS);
+    // absolute slack of the box tests: 64u x (an upper bound of |c - centre of any box|)
+    const float reach = ((fabsf(cx - M.obb_cm[0]) + fabsf(cy - M.obb_cm[1])) + fabsf(cz - M.obb_cm[2])) + (M.obb_rm + rho);
+    const float Ew = 3.8146973e-6f * reach;
+    const float X2 = -2.f * qx, Y2 = -2.f * qy, Z2 = -2.f * qz;
+    const float c2 = M.amb_c2;
+    float rr;  // per lane: sqrt of the lane's threshold, with the slack of the plane test
+#define SDFK_PK_REFRESH()                                                                           \
+    {                                                                                               \
+        const float thr_ = APPROX ? fmaxf(SA.B1 + Qe, 0.f) * cm : __uint_as_float(SE.b) * c2;       \
+        rr = __builtin_fmaf(__builtin_amdgcn_sqrtf(thr_), 1.f + PK_EPS, PK_EPS * rho);              \
+    }
+#define SDFK_PK_EVAL(REF)                                 \
+    {                                                     \
+        SDFK_COUNT(2, 1);                                 \
+        SDFK_COUNT(3, (REF) & 15u);                       \
+        work += (REF) & 15u;                              \
+        if (APPROX)                                       \
+            group_approx(M, X2, Y2, Z2, (REF), SA);       \
+        else                                              \
+            group_exact(M, qx, qy, qz, (REF), SE);        \
+        SDFK_PK_REFRESH()                                 \
+    }
+    uint32_t work = 0;  // chunks evaluated + candidates tested so far (wave-uniform)
+    const uint32_t nrows = (M.kd_nl1 + 63u) >> 6;
+    // ---- greedy descent: the nearest L1 node, its nearest group; evaluating it gives every lane a bound
+    uint32_t j0, g0;
+    float gx, gy, gz;
+    {
+        uint32_t bkey = 0xFFFFFFFFu, brow = 0u;
+        for (uint32_t row = 0; row < nrows; ++row) {
+            const ObbLane o = obb_wide<false>(M.kd_l1obb + 256u * (size_t)row, lane, cx, cy, cz, Ew);
+            const uint32_t key = obb_key(o.dP, 64u * row + lane < M.kd_nl1);
+            if (key < bkey) bkey = key, brow = row;
+        }
+        SDFK_COUNT(1, nrows);
+        const uint32_t mkey = wave_umin(bkey);
+        const uint32_t who = (uint32_t)__builtin_ctzll(__ballot(bkey == mkey));
+        j0 = 64u * (uint32_t)__builtin_amdgcn_readlane((int)brow, (int)who) + who;
+        const uint32_t cnt = min(64u, M.kd_ngroups - 64u * j0);
+        const ObbLane o = obb_wide<true>(M.kd_gobb + 256u * (size_t)j0, lane, cx, cy, cz, Ew);
+        SDFK_COUNT(1, 1);
+        const uint32_t key = obb_key(o.dP, lane < cnt);
+        const uint32_t mk = wave_umin(key);
+        g0 = (uint32_t)__builtin_ctzll(__ballot(key == mk));
+        const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)o.tag, (int)g0);
+        SDFK_PK_EVAL(ref)
+        // Across the packet the thresholds follow the distance field, rr_l ~ r0 + g.e_l with g the
+        // direction away from the nearest patch: the packet-level tests bound rr_l - g.e_l instead of
+        // rr_l alone (any g is valid; this one makes the residual small in the far field).
+        gx = wave_readf(o.nx, g0), gy = wave_readf(o.ny, g0), gz = wave_readf(o.nz, g0);
+        if (!(fabsf(gx) <= 1.f && fabsf(gy) <= 1.f && fabsf(gz) <= 1.f)) gx = gy = gz = 0.f;
+    }
+#if SDFK_EXP == 1
+    return false;
+#endif
+    // ---- the walk: L1 rows -> candidate L1 nodes -> candidate groups -> plane test -> evaluation
+    // packet-level threshold: max over the lanes of rr_l - g.e_l (+ slack of the dot product)
+#define SDFK_PK_RES() \
+    (pk_ord2f(wave_umax(pk_f2ord(rr - __builtin_fmaf(gx, ex, __builtin_fmaf(gy, ey, gz * ez))))) + 2.f * PK_EPS * rho)
+#ifndef SDFK_ORD_L
+#define SDFK_ORD_L 1
+#endif
+#ifndef SDFK_ORD_G
+#define SDFK_ORD_G 1
+#endif
+    // Children are taken nearest first (by their packet-level bound): the thresholds are final after
+    // the first few groups, and once the nearest remaining child fails the packet-level test all do.
+    for (uint32_t row = 0; row < nrows; ++row) {
+        const ObbLane o1 = obb_wide<true>(M.kd_l1obb + 256u * (size_t)row, lane, cx, cy, cz, Ew, gx, gy, gz, rho);
+        SDFK_COUNT(1, 1);
+        float res = SDFK_PK_RES();
+        bool alive1 = 64u * row + lane < M.kd_nl1 && !(o1.pk > res);
+        unsigned long long m1 = __ballot(alive1);
+        for (;;) {
+            uint32_t k;
+            if (SDFK_ORD_L) {
+                const uint32_t key = alive1 ? pk_f2ord(o1.pk) : 0xFFFFFFFFu;
+                const uint32_t mk = wave_umin(key);
+                if (mk == 0xFFFFFFFFu || pk_ord2f(mk) > res) break;
+                k = (uint32_t)__builtin_ctzll(__ballot(key == mk));
+                if (lane == k) alive1 = false;
             } else {
-                const uint32_t u0 = __float_as_uint(lb0), u1 = __float_as_uint(lb1),
-                               u2 = __float_as_uint(lb2), u3 = __float_as_uint(lb3);
-                const bool a_first = (int)__popcll(__ballot(min(u0, u1) <= min(u2, u3))) >= 32;
-                const bool s01 = (int)__popcll(__ballot(u0 <= u1)) >= 32;
-                const bool s23 = (int)__popcll(__ballot(u2 <= u3)) >= 32;
-                uint32_t last = 0;
-#define SDFK_PK_PUSH(K)                                              \
-    if (act & (1u << K)) {                                           \
-        stk.lb[sp * 64u + lane] = (uint16_t)(u##K >> 16);            \
-        stk.ref[sp] = r##K;                                          \
-        last = r##K;                                                 \
-        ++sp;                                                        \
-    }
-#define SDFK_PK_ORDER(A, B, C, D) { SDFK_PK_PUSH(D) SDFK_PK_PUSH(C) SDFK_PK_PUSH(B) SDFK_PK_PUSH(A) }
-                if (a_first) {
-                    if (s01) {
-                        if (s23) SDFK_PK_ORDER(0, 1, 2, 3) else SDFK_PK_ORDER(0, 1, 3, 2)
-                    } else {
-                        if (s23) SDFK_PK_ORDER(1, 0, 2, 3) else SDFK_PK_ORDER(1, 0, 3, 2)
-                    }
-                } else {
-                    if (s01) {
-                        if (s23) SDFK_PK_ORDER(2, 3, 0, 1) else SDFK_PK_ORDER(3, 2, 0, 1)
-                    } else {
-                        if (s23) SDFK_PK_ORDER(2, 3, 1, 0) else SDFK_PK_ORDER(3, 2, 1, 0)
-                    }
-                }
-#undef SDFK_PK_ORDER
-#undef SDFK_PK_PUSH
-                --sp;
-                cur = last;
+                if (!m1) break;
+                k = (uint32_t)__builtin_ctzll(m1);
+                m1 &= m1 - 1ull;
+                if (wave_readf(o1.pk, k) > res) continue;
             }
-        } else {
-            const uint32_t nch = cur & 15u;
-            const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
-            work += nch;
-            SDFK_COUNT(2, 1);
-            SDFK_COUNT(3, nch);
-            if (nch) {
-                const u32x16* C = (const u32x16*)__builtin_assume_aligned(M.kd_pts4 + first, 64);
-                float gm = INF;  // (a NaN never enters: fminf keeps the other operand)
-                for (uint32_t ci = 0; ci < nch; ++ci) {
-                    const u32x16 A = C[ci];
-#define SDFK_APX_SLOT(O_)                                                                  \
-    __builtin_fmaf(X2, __uint_as_float(A[O_]),                                             \
-                   __builtin_fmaf(Y2, __uint_as_float(A[O_ + 1]),                          \
-                                  __builtin_fmaf(Z2, __uint_as_float(A[O_ + 2]), __uint_as_float(A[O_ + 3]))))
-                    // 12 FMA + 2 v_min3 per chunk (a NaN operand is dropped by min3 as by min)
-                    const float a0 = SDFK_APX_SLOT(0), a1 = SDFK_APX_SLOT(4), a2 = SDFK_APX_SLOT(8),
-                                a3 = SDFK_APX_SLOT(12);
-                    gm = fmin3(gm, a0, a1);
-                    gm = fmin3(gm, a2, a3);
-#undef SDFK_APX_SLOT
-                }
-                // sorted insert of this group's minimum into B1..B4 (+ the groups of the first three);
-                // skipped when no lane's top four change (the insert is then the identity)
-                if (__ballot(gm < B4) != 0ull) {
-                const bool c1 = gm < B1, c2 = gm < B2, c3 = gm < B3;
-                H3 = c2 ? H2 : (c3 ? cur : H3);
-                H2 = c1 ? H1 : (c2 ? cur : H2);
-                H1 = c1 ? cur : H1;
-                float t = fmaxf(B1, gm);
-                B1 = fminf(B1, gm);
-                float t2 = fmaxf(B2, t);
-                B2 = fminf(B2, t);
-                t = fmaxf(B3, t2);
-                B3 = fminf(B3, t2);
-                B4 = fminf(B4, t);
-                }
-            }
-            need_pop = true;
-        }
-        if (need_pop) {
-            const uint32_t thr16 = __float_as_uint(fmaxf(B1 + Qe, 0.f) * cm) >> 16;
-            const bool over = work > M.heavy_budget;
-            if (over) sp = 0;
+            const uint32_t j = 64u * row + k;
+            const uint32_t cnt = min(64u, M.kd_ngroups - 64u * j);
+            const ObbLane o = obb_wide<true>(M.kd_gobb + 256u * (size_t)j, lane, cx, cy, cz, Ew, gx, gy, gz, rho);
+            SDFK_COUNT(1, 1);
+            bool alive = lane < cnt && !(o.pk > res) && !(j == j0 && lane == g0);  // (g0: evaluated by the greedy descent)
+            unsigned long long m2 = __ballot(alive);
             for (;;) {
-                if (sp == 0) return ApproxLane{B1, B2, B3, B4, H1, H2, H3, over};
-                --sp;
-                SDFK_COUNT(5, 1);
-                const uint32_t l16 = stk.lb[sp * 64u + lane];
-                const uint32_t r = stk.ref[sp];
-                if (__ballot(l16 <= thr16) != 0ull) {
-                    cur = r;
-                    break;
+                uint32_t g;
+                if (SDFK_ORD_G) {
+                    const uint32_t key = alive ? pk_f2ord(o.pk) : 0xFFFFFFFFu;
+                    const uint32_t mk = wave_umin(key);
+                    if (mk == 0xFFFFFFFFu || pk_ord2f(mk) > res) break;
+                    g = (uint32_t)__builtin_ctzll(__ballot(key == mk));
+                    if (lane == g) alive = false;
+                } else {
+                    if (!m2) break;
+                    g = (uint32_t)__builtin_ctzll(m2);
+                    m2 &= m2 - 1ull;
                 }
+                SDFK_COUNT(5, 1);
+                ++work;
+                const float t = __builtin_fmaf(wave_readf(o.nx, g), ex,
+                                               __builtin_fmaf(wave_readf(o.ny, g), ey,
+                                                              __builtin_fmaf(wave_readf(o.nz, g), ez, wave_readf(o.f0, g))));
+                if (__ballot(!(t > rr)) == 0ull) continue;
+                const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)o.tag, (int)g);
+                SDFK_PK_EVAL(ref)
+                if (work > M.heavy_budget) return true;  // give up (wave-uniform): k_query_heavy takes over
+                res = SDFK_PK_RES();  // tightened
             }
         }
     }
+#undef SDFK_PK_RES
+#undef SDFK_PK_EVAL
+#undef SDFK_PK_REFRESH
+    return false;
 }
 
 // exact evaluation of one packet group for one lane (second phase of the approximate pass): the
@@ -519,14 +611,9 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
                                                          int trunc_aabb, void* __restrict__ out,
                                                          unsigned long long* __restrict__ amb_mask,
                                                          uint32_t* __restrict__ amb_cnt,
-                                                         uint32_t depth_cap, uint32_t off,
+                                                         uint32_t off,
                                                          uint32_t* __restrict__ heavy_list,
                                                          uint32_t* __restrict__ heavy_cnt) {
-    extern __shared__ uint32_t lds[];
-    // per wave: depth_cap rows of 64 x u16 lower bounds, then depth_cap refs
-    PacketStack stk;
-    stk.lb = (uint16_t*)(lds + (threadIdx.x >> 6) * depth_cap * 33u);
-    stk.ref = lds + (threadIdx.x >> 6) * depth_cap * 33u + depth_cap * 32u;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     // lanes past the end of the batch repeat its last query (and write nothing): they then ask
@@ -542,20 +629,23 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
         return;
     }
     PacketBest pb;
-    ApproxLane A;
+    ExactState SE = {0x7F7FFFFFu, 0x7F7FFFFFu, H_NONE, 0xFFFFFFFFu};  // FLT_MAX bits (KNNResultSet::init)
+    const float INF = __builtin_inff();
+    ApproxState A = {INF, INF, INF, INF, H_NONE, H_NONE, H_NONE};
     float Qf = 0.f, Ea = 0.f;
     if (APPROX) {
-        // error model of a() for this lane (see kd_nearest_packet_approx)
+        // error model of a() for this lane (see "Approximate first pass")
         const float u = 5.9604645e-8f;  // 2^-24
         const float Vx = fmaxf(fabsf(M.bb[0]), fabsf(M.bb[3])), Vy = fmaxf(fabsf(M.bb[1]), fabsf(M.bb[4])),
                     Vz = fmaxf(fabsf(M.bb[2]), fabsf(M.bb[5]));
         const float S = M.vmax2 + 2.f * ((fabsf(p.x) * Vx + fabsf(p.y) * Vy) + fabsf(p.z) * Vz);
         Qf = (p.x * p.x + p.y * p.y) + p.z * p.z;
         Ea = u * (5.f * S + 4.f * Qf);
-        A = kd_nearest_packet_approx(M, p.x, p.y, p.z, Qf + Ea, (1.f + 8.f * u) * M.amb_c2, stk);
-        pb.bailed = A.bailed;
+        pb.bailed = packet_walk<true>(M, p.x, p.y, p.z, Qf + Ea, (1.f + 8.f * u) * M.amb_c2, SE, A);
     } else {
-        pb = kd_nearest_packet(M, p.x, p.y, p.z, stk);
+        pb.bailed = packet_walk<false>(M, p.x, p.y, p.z, 0.f, 1.f, SE, A);
+        if (SE.b == SE.tieb) SE.s2 = SE.b;  // a settled exact tie is a tie
+        pb.b = __uint_as_float(SE.b), pb.s = __uint_as_float(SE.s2), pb.h = SE.h;
     }
     if (pb.bailed) {  // wave-uniform: every query of this wave goes to the heavy list (absolute indices)
         const unsigned long long vm = __ballot(valid);
@@ -570,6 +660,9 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
         if (valid) heavy_list[base + (uint32_t)__popcll(vm & lt)] = off + (uint32_t)src;
         return;
     }
+#if SDFK_EXP == 2 || SDFK_EXP == 3
+    if (KIND == Q_NN) { if (valid) ((int32_t*)out)[src] = APPROX ? (int)A.H1 : (int)SE.h; if ((threadIdx.x & 63) == 0) amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u; return; }
+#endif
     // pb.h is nanoflann's answer iff nanoflann does not prune it before visiting it:
     //  (1) no other vertex within b * c (c - 1 ~ 4.5e-6): impossible, see k_query_packet header;
     //  (2) otherwise measure it: every bound tested on the way to pb.h is <= the distance of

@@ -17,8 +17,12 @@ struct MeshDev {
     // vertex kd-tree: 64 B nodes {box1 lo/hi, box2 lo/hi, divlow, divhigh, ref1|feat, ref2}
     const float4* kd_pn;
     const uint32_t* kd_split;
-    const float4* kd_qn;  // 4-wide collapse for the packet pass: 128 B {box[4][6], ref[4], pad}
-    uint32_t kd_qroot;
+    // wide packet walk: oriented boxes of the packet groups and of the runs of 64 groups (L1 nodes),
+    // 64 B each, stored [node][4][64] float4 so that lane k reads child k with unit stride
+    const float4* kd_gobb;   // [kd_nl1][4][64]
+    const float4* kd_l1obb;  // [ceil(kd_nl1 / 64)][4][64]
+    uint32_t kd_ngroups, kd_nl1;
+    float obb_cm[3], obb_rm;  // centre of the mesh AABB, sum of its extents (rounding slack of the box tests)
     int fast;  // "fast_nn": GPU-built tree, exact distances, ties go to the lowest tree position
     const int32_t* kd_vind;
     uint32_t kd_root;

@@ -15,7 +15,8 @@
 //   rnodes     32 B / node: threaded (stackless, pre-order + skip link) LBVH over the
 //              rotated-frame face AABBs (x+ tie-break ray); Morton codes -> LDS radix sort ->
 //              Karras hierarchy, refit on update()
-//   kd_qn      128 B / 4-wide node of the packet pass (two kd levels collapsed, leaf groups)
+//   kd_gobb    64 B / packet group and kd_l1obb 64 B / run of 64 groups: oriented boxes of the wide
+//              packet walk (lane k tests child k against the packet of 64 queries)
 // One translation unit, in parts (included in this order):
 //   kernels_query.h   device views, strict (nanoflann-exact) search, ray parity, k_query
 //   kernels_packet.h  packet pass (k_query_packet, the dominant kernel), k_fb_compact, k_query_heavy
@@ -145,8 +146,11 @@ struct sdfhip_ctx {
     float* d_verts = nullptr;
     uint32_t* d_faces = nullptr;
     float4* d_kd_pn = nullptr;
-    float4* d_kd_qn = nullptr;
-    size_t kd_quads_cap = 0;
+    uint32_t* d_kd_gref = nullptr;  // packet groups in position order (refs)
+    float4* d_kd_gobb = nullptr;    // their oriented boxes, [n_l1][4][64]
+    float4* d_kd_l1obb = nullptr;   // boxes of the runs of 64 groups, [rows][4][64]
+    size_t kd_groups_cap = 0;
+    uint32_t n_groups = 0, n_l1 = 0;
     uint32_t* d_kd_split = nullptr;
     std::vector<float> perm_pts4;  // host staging of kd_pts4, kept across updates
     int32_t* d_kd_vind = nullptr;
@@ -183,7 +187,6 @@ struct sdfhip_ctx {
     // fast_nn mode (GPU-built vertex tree)
     int64_t opt_fast_nn = 0;   // applies at the next update
     bool fast_active = false;  // what the structures on the device currently are
-    uint32_t fast_qroot = KD_LEAF, fast_levels = 1, fast_quads = 0;
     uint32_t* d_vkeys = nullptr;
     uint32_t* d_vidx = nullptr;
     size_t vkeys_cap = 0;
@@ -443,26 +446,40 @@ int update_device_side(sdfhip_ctx* h) {
     return 0;
 }
 
+// (re)allocates the group arrays and builds the oriented boxes of the wide packet walk from the group
+// refs in d_kd_gref (kd_pts4 / kd_vind must be current on the stream)
+int reserve_groups(sdfhip_ctx* h, uint32_t ngroups) {
+    if ((size_t)ngroups > h->kd_groups_cap) {
+        const size_t cap = (size_t)ngroups + ngroups / 8 + 64;
+        const size_t nl1 = (cap + 63) / 64, rows = (nl1 + 63) / 64;
+        if (int rc = dalloc(&h->d_kd_gref, cap)) return rc;
+        if (int rc = dalloc(&h->d_kd_gobb, 256 * nl1)) return rc;
+        if (int rc = dalloc(&h->d_kd_l1obb, 256 * rows)) return rc;
+        // lanes past the last child read (and ignore) what lies there: keep it defined
+        HIPC(hipMemsetAsync(h->d_kd_gobb, 0, sizeof(float4) * 256 * nl1, h->stream));
+        HIPC(hipMemsetAsync(h->d_kd_l1obb, 0, sizeof(float4) * 256 * rows, h->stream));
+        h->kd_groups_cap = cap;
+    }
+    return 0;
+}
+int build_obbs(sdfhip_ctx* h, uint32_t ngroups) {
+    hipStream_t s = h->stream;
+    h->n_groups = ngroups;
+    h->n_l1 = (ngroups + 63u) / 64u;
+    if (ngroups == 0) return 0;
+    k_group_obb<<<(ngroups + 63) / 64, 64, 0, s>>>(h->d_kd_gref, ngroups, h->d_kd_pts4, h->d_kd_vind, h->d_kd_gobb);
+    k_l1_obb<<<h->n_l1, 64, 0, s>>>(h->d_kd_gref, ngroups, h->d_kd_pts4, h->d_kd_vind, h->d_kd_l1obb);
+    HIPC(hipGetLastError());
+    return 0;
+}
+
 // fast_nn: vertex tree of the packet pass built on the device (d_verts and aabb are current)
 int build_fast_tree(sdfhip_ctx* h) {
     hipStream_t s = h->stream;
     const uint32_t nv = h->nv;
     const uint32_t ngroups = (nv + FAST_GROUP - 1) / FAST_GROUP;
     const size_t nalloc = (size_t)FAST_GROUP * ngroups + 16;
-    // level sizes of the implicit 4-ary tree over the groups, leaves first; the root is last
-    uint32_t level_n[20];
-    uint32_t levels = 0, total = 0;
-    for (uint32_t c = ngroups; levels == 0 || c > 1;) {
-        c = (c + 3) / 4;
-        if (c == 0) c = 1;
-        level_n[levels++] = c;
-        total += c;
-        if (c == 1) break;
-    }
-    if (total > h->kd_quads_cap) {
-        if (int rc = dalloc(&h->d_kd_qn, 8 * (size_t)total)) return rc;
-        h->kd_quads_cap = total;
-    }
+    if (int rc = reserve_groups(h, ngroups)) return rc;
     if (nalloc > h->kd_pos_cap) {
         if (int rc = dalloc(&h->d_kd_pts4, nalloc)) return rc;
         if (int rc = dalloc(&h->d_kd_vind, nalloc)) return rc;
@@ -487,20 +504,9 @@ int build_fast_tree(sdfhip_ctx* h) {
     k_fast_positions<<<(uint32_t)((nalloc + 255) / 256), 256, 0, s>>>(h->d_verts, sorted_idx, nv,
                                                                       (uint32_t)nalloc, h->d_kd_pts4,
                                                                       h->d_kd_vind);
-    k_fast_quads_leaf<<<(level_n[0] + 63) / 64, 64, 0, s>>>(h->d_kd_pts4, nv, ngroups, level_n[0], h->d_kd_qn);
-    uint32_t child_off = 0;
-    for (uint32_t l = 1; l < levels; ++l) {
-        const uint32_t off = child_off + level_n[l - 1];
-        k_fast_quads_inner<<<(level_n[l] + 63) / 64, 64, 0, s>>>(h->d_kd_qn + 8 * (size_t)child_off,
-                                                                 level_n[l - 1], child_off, level_n[l],
-                                                                 h->d_kd_qn + 8 * (size_t)off);
-        child_off = off;
-    }
+    if (ngroups) k_fast_grefs<<<(ngroups + 255) / 256, 256, 0, s>>>(nv, ngroups, h->d_kd_gref);
     HIPC(hipGetLastError());
-    h->fast_qroot = total - 1;
-    h->fast_levels = levels;
-    h->fast_quads = total;
-    return 0;
+    return build_obbs(h, ngroups);
 }
 
 // The approximate first pass of the packet kernel orders vertices by a() = |v|^2 - 2 q.v, whose
@@ -606,17 +612,14 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
         return vmax2;
     });
     auto tq0 = std::chrono::steady_clock::now();
-    h->kd.build_quads();
+    h->kd.build_groups();
     h->vmax2 = std::nextafter(fill.get(), FLT_MAX);
     auto tq1 = std::chrono::steady_clock::now();
     const int rc_dev = dev_side.get();
     auto tq2 = std::chrono::steady_clock::now();
     if (rc_dev) return fail(rc_dev, "%s", dev_err.empty() ? "device-side update failed" : dev_err.c_str());
     if (h->kd.nodes.size() >= (size_t)KD_MARK) return fail(SDFHIP_E_INVALID, "kd-tree too large");
-    if (h->kd.quads.size() > h->kd_quads_cap) {
-        if (int rc = dalloc(&h->d_kd_qn, 8 * h->kd.quads.size())) return rc;
-        h->kd_quads_cap = h->kd.quads.size();
-    }
+    if (int rc = reserve_groups(h, (uint32_t)h->kd.groups.size())) return rc;
     if (h->kd.nodes.size() > h->kd_nodes_cap) {
         if (int rc = dalloc(&h->d_kd_pn, 4 * h->kd.nodes.size())) return rc;
         if (int rc = dalloc(&h->d_kd_split, h->kd.nodes.size())) return rc;
@@ -647,9 +650,11 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
                             hipMemcpyHostToDevice, s));
         HIPC(hipMemcpyAsync(h->d_kd_split, h->kd.split.data(), sizeof(uint32_t) * h->kd.split.size(),
                             hipMemcpyHostToDevice, s));
-        HIPC(hipMemcpyAsync(h->d_kd_qn, h->kd.quads.data(), sizeof(sdfk::KdQuadH) * h->kd.quads.size(),
-                            hipMemcpyHostToDevice, s));
     }
+    if (!h->kd.groups.empty())
+        HIPC(hipMemcpyAsync(h->d_kd_gref, h->kd.groups.data(), sizeof(uint32_t) * h->kd.groups.size(),
+                            hipMemcpyHostToDevice, s));
+    if (int rc = build_obbs(h, (uint32_t)h->kd.groups.size())) return rc;
     HIPC(hipStreamSynchronize(s));  // host arrays are pageable and rebuilt by the next update
     h->last_update_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -666,8 +671,15 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     MeshDev M;
     M.kd_pn = h->d_kd_pn;
     M.kd_split = h->d_kd_split;
-    M.kd_qn = h->d_kd_qn;
-    M.kd_qroot = h->fast_active ? h->fast_qroot : h->kd.quad_root;
+    M.kd_gobb = h->d_kd_gobb;
+    M.kd_l1obb = h->d_kd_l1obb;
+    M.kd_ngroups = h->n_groups;
+    M.kd_nl1 = h->n_l1;
+    M.obb_rm = 0.f;
+    for (int d = 0; d < 3; ++d) {
+        M.obb_cm[d] = 0.5f * (h->aabb[d] + h->aabb[d + 3]);
+        M.obb_rm += h->aabb[d + 3] - h->aabb[d];
+    }
     M.fast = h->fast_active ? 1 : 0;
     M.kd_vind = h->d_kd_vind;
     M.kd_root = h->fast_active ? KD_LEAF : h->kd.root_ref;
@@ -798,8 +810,6 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     const bool sort_any = h->opt_sort && n >= sort_min;
     // packet stack: <= 3 deferred slots per 4-wide level (+ the transient 4th); 132 B per slot
     const bool fast = h->fast_active;  // GPU-built tree: the packet kernel is the only nn search
-    const int qdepth = fast ? (int)h->fast_levels : h->kd.quad_depth;
-    const uint32_t pstack = 3u * (uint32_t)(qdepth > 0 ? qdepth : 1) + 4u;
     // Small batches.  A tree walk is a chain of dependent loads: ~2 ms for ONE far-field query on a
     // 180k-vertex tree, whether a lane walks alone (strict kernel) or a wave walks for 64 sparse
     // queries (their union is most of the tree).  While n x positions is small the exact scan of
@@ -843,7 +853,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         return 0;
     }
     const bool packet_any =
-        KIND != Q_DETAIL && (fast || (sort_any && h->opt_packet && pstack * 132u <= 48u * 1024u));
+        KIND != Q_DETAIL && (fast || (sort_any && h->opt_packet));
     const int64_t fb_cap = packet_any ? (n < (1ll << 27) ? n : (1ll << 27)) : 0;
     if (sort_any || fast)
         if (int rc = reserve_query_ws(h, n < chunk ? n : chunk, fb_cap)) return rc;
@@ -911,19 +921,18 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         if (packet_any && (perm || fast)) {
             if (deferred_pts + m > h->fb_cap)
                 if (int rc = flush()) return rc;
-            const size_t lds = (size_t)(PBLOCK / 64) * pstack * 33u * sizeof(uint32_t);
             constexpr int PK = KIND == Q_DETAIL ? Q_NN : KIND;
             ProfScope prof{h, s};  // the dominant kernel, one event pair per launch
             if (int rc = prof.begin()) return rc;
             // strict mode: approximate first pass + exact second phase (kernels_packet.h); the GPU-built
             // tree of fast_nn has no strict kernel behind it and keeps the exact walk
             if (!fast && (h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0))
-                k_query_packet<PK, ROBUST, true><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, lds, s>>>(
-                    M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, pstack, (uint32_t)off,
+                k_query_packet<PK, ROBUST, true><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, 0, s>>>(
+                    M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, (uint32_t)off,
                     h->d_fb_list + h->fb_cap, h->d_fb_count + 2);
             else
-                k_query_packet<PK, ROBUST, false><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, lds, s>>>(
-                    M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, pstack, (uint32_t)off,
+                k_query_packet<PK, ROBUST, false><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, 0, s>>>(
+                    M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, (uint32_t)off,
                     h->d_fb_list + h->fb_cap, h->d_fb_count + 2);
             if (int rc = prof.end(m)) return rc;
             if (fast) {  // no near-tie deferral in this mode, only the heavy list
@@ -1304,7 +1313,7 @@ void sdfhip_destroy(sdfhip_t* h) {
         if (h->query_pending) (void)hipEventSynchronize(h->ev_query);  // a caller-stream query may still run
         (void)hipEventDestroy(h->ev_query);
     }
-    void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_qn, h->d_kd_vind, h->d_adj_off,
+    void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_gref, h->d_kd_gobb, h->d_kd_l1obb, h->d_kd_vind, h->d_adj_off,
                     h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
@@ -1456,8 +1465,8 @@ int sdfhip_adj_faces(const sdfhip_t* h, uint32_t v, const int32_t** ids) {
 }
 int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* o) {
     if (!h || !o) return fail(SDFHIP_E_INVALID, "null handle/out");
-    o->kd_nodes = h->fast_active ? (int32_t)h->fast_quads : (int32_t)h->kd.nodes.size();
-    o->kd_depth = h->fast_active ? (int32_t)h->fast_levels : h->kd.depth;
+    o->kd_nodes = h->fast_active ? (int32_t)h->n_groups : (int32_t)h->kd.nodes.size();
+    o->kd_depth = h->fast_active ? 2 : h->kd.depth;
     o->bvh_nodes = h->robust ? (int32_t)h->n_rnodes : 0;
     o->bvh_depth = (int32_t)h->bvh_depth;
     o->last_update_ms = h->last_update_ms;

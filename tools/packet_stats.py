@@ -2,7 +2,7 @@
 """Per-wave work of the packet pass (needs `make -C sdf_amd/csrc stats`; SDFHIP_LIB is set here)."""
 import argparse, os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["SDFHIP_LIB"] = os.path.join(ROOT, "sdf_amd", "libsdfhip_stats.so")
+os.environ["SDFHIP_LIB"] = os.environ.get("SDFHIP_STATS_LIB", os.path.join(ROOT, "sdf_amd", "libsdfhip_stats.so"))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import sdf_amd
