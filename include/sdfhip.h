@@ -83,6 +83,20 @@ int sdfhip_sdf(sdfhip_t* h, const float* points, int64_t n, int trunc_aabb, floa
 int sdfhip_sdf_device(sdfhip_t* h, const float* d_points, int64_t n, int trunc_aabb,
                       float* d_out, void* stream);
 
+/* sdfhip_sdf_device for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments and the
+ * same results as sdfhip_sdf_device, but the call allocates nothing (no hipMalloc / hipFree, no
+ * event or stream creation): every intermediate buffer (query sort keys and permutation, radix-sort
+ * histograms, deferred-query lists and their counters) lives in one static device array of 26 MiB
+ * that each GPU the library runs on holds until the process ends.  Limit: at most
+ * SDFHIP_NOALLOC_MAX_POINTS points per call (more: SDFHIP_E_INVALID); meshes whose kd-tree is
+ * deeper than 40 levels are refused (SDFHIP_E_STATE).  All calls on one GPU — from any handle —
+ * share that array: calls that overlap on one GPU (different handles on different streams) race;
+ * calls on one handle are ordered as usual. */
+#define SDFHIP_NOALLOC_MAX_POINTS (1 << 20)
+int sdfhip_sdf_device_noalloc(sdfhip_t* h, const float* d_points, int64_t n, int trunc_aabb,
+                              float* d_out, void* stream);
+
 /* Replaces SDF::contains(points, n_threads) -> Impl::contains (sdf.cpp:385-389, 160-174). */
 int sdfhip_contains(sdfhip_t* h, const float* points, int64_t n, uint8_t* out);
 int sdfhip_contains_device(sdfhip_t* h, const float* d_points, int64_t n, uint8_t* d_out,

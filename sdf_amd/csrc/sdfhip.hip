@@ -125,6 +125,23 @@ struct GridBuf {
     }
 };
 
+// Device workspace of one query call: Morton keys / permutation of the query sort (+ the sorter's
+// alternates and histograms), the per-wave masks of deferred queries, the deferred / heavy lists.
+struct QueryWs {
+    uint32_t* qkeys = nullptr;
+    uint32_t* qperm = nullptr;
+    uint32_t* qbounds = nullptr;
+    unsigned long long* amb_mask = nullptr;
+    uint32_t* amb_cnt = nullptr;
+    uint32_t* amb_s1 = nullptr;
+    uint32_t* amb_s2 = nullptr;
+    uint32_t* fb_list = nullptr;   // [0, cap): deferred near-tie queries; [cap, 2 cap): heavy-wave queries
+    uint32_t* fb_count = nullptr;  // [0], [1] length of the deferred list (ping-pong, see k_fb_compact), [2] heavy list
+    int64_t q_cap = 0, fb_cap = 0;
+    RadixSorter sorter;
+    bool fixed = false;  // carved out of the static scratch array: never grown, never freed
+};
+
 struct sdfhip_ctx {
     int device = 0;
     bool robust = true, own = false;
@@ -157,17 +174,12 @@ struct sdfhip_ctx {
     size_t kd_nodes_cap = 0, kd_pos_cap = 0;
     float4* d_kd_pts4 = nullptr;
     float amb_c = 1.f, amb_c2 = 1.f;
-    uint32_t* d_fb_list = nullptr;
-    uint32_t* d_fb_count = nullptr;  // two words, ping-pong (see k_fb_compact)
-    int64_t fb_cap = 0;
-    uint32_t last_fb = 0;  // length of the last deferred list (read back only while profiling)
-    uint32_t last_heavy = 0;  // queries of the last call's heavy waves (same)
+    QueryWs ws;            // this handle's own query workspace, grown on demand
+    QueryWs* W = &ws;      // the workspace of the running call (the static scratch in the no-alloc entry)
+    uint32_t* h_counts = nullptr;  // page-locked: [0] length of the last deferred list, [1] queries of the
+                                   // last call's heavy waves (read back only while profiling)
     int64_t opt_heavy_budget = 0;  // chunks per wave before it gives up; 0 = automatic
     int64_t opt_scan_max = -1;  // n x positions up to which a batch is answered by the exact scan; -1 = automatic
-    unsigned long long* d_amb_mask = nullptr;
-    uint32_t* d_amb_cnt = nullptr;
-    uint32_t* d_amb_s1 = nullptr;
-    uint32_t* d_amb_s2 = nullptr;
     int64_t opt_packet = 1;
     int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
     bool approx_ok = false;   // decided by every update(): see approx_pays()
@@ -202,14 +214,8 @@ struct sdfhip_ctx {
     uint32_t bvh_depth = 0;
     bool topo_built = false;
     float topo_R[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // rotation the LBVH topology was built for
-    RadixSorter sorter;
-    // query workspace
-    uint32_t* d_qkeys = nullptr;
-    uint32_t* d_qperm = nullptr;
-    uint32_t* d_qbounds = nullptr;
-    uint32_t* d_gstack = nullptr;
+    uint32_t* d_gstack = nullptr;  // strict kernel, trees deeper than LDS_DEPTH_MAX
     size_t gstack_words = 0;
-    int64_t q_cap = 0;
     // options
     int64_t opt_sort = 1, opt_sort_min = 8192, opt_chunk = 1 << 27;
     int64_t opt_sort_min_contains = 12000000;  // robust contains(): see run_query_t
@@ -238,7 +244,74 @@ struct sdfhip_ctx {
     int64_t prof_launches = 0, prof_points = 0;
 };
 
+// =========================================================================================
+// Static scratch of the allocation-free entry point (sdfhip_sdf_device_noalloc).
+// Every GPU the library runs on holds its own copy of this array, at its own address, until the
+// process ends.  In host code the array's NAME is only a stand-in, not a device address: the
+// address is taken once per device with hipGetSymbolAddress (that device current) and host code
+// uses that pointer everywhere — kernel arguments, hipMemsetAsync.  All calls on one GPU share
+// the array and it keeps the last call's contents: the pipeline clears what must start at zero
+// (the three list counters), and calls that overlap on one GPU race.
+// =========================================================================================
+constexpr int64_t NOALLOC_MAX_POINTS = SDFHIP_NOALLOC_MAX_POINTS;
+constexpr size_t SCRATCH_BYTES = (size_t)26 << 20;  // 24 B per point + histograms, see scratch_carve
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
 namespace {
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+QueryWs* g_scratch_ws[MAX_DEVICES] = {};  // per device; built once, never freed (static storage behind it)
+
+// lays the workspace of a query call of up to NOALLOC_MAX_POINTS points out in `base`
+int scratch_carve(unsigned char* base, QueryWs* W) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char* p = base + off;
+        off = (off + bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    const size_t n = (size_t)NOALLOC_MAX_POINTS, nw = n / 64 + 4;
+    const size_t ntiles = (n + RS_TILE - 1) / RS_TILE, nh = 256 * ntiles;
+    const size_t n1 = (nh + 2047) / 2048, n2 = (n1 + 2047) / 2048;
+    W->qkeys = (uint32_t*)take(4 * n);
+    W->qperm = (uint32_t*)take(4 * n);
+    W->sorter.keys_alt = (uint32_t*)take(4 * n);
+    W->sorter.vals_alt = (uint32_t*)take(4 * n);
+    W->sorter.hist = (uint32_t*)take(4 * nh);
+    W->sorter.sums1 = (uint32_t*)take(4 * (n1 + 1));
+    W->sorter.sums2 = (uint32_t*)take(4 * (n2 + 1));
+    W->sorter.cap = (uint32_t)n;
+    W->fb_list = (uint32_t*)take(4 * 2 * n);
+    W->amb_mask = (unsigned long long*)take(8 * nw);
+    W->amb_cnt = (uint32_t*)take(4 * nw);
+    W->amb_s1 = (uint32_t*)take(4 * (nw / 2048 + 4));
+    W->amb_s2 = (uint32_t*)take(4 * (nw / 2048 / 2048 + 4));
+    W->qbounds = (uint32_t*)take(4 * 8);
+    W->fb_count = (uint32_t*)take(4 * 4);
+    W->q_cap = W->fb_cap = (int64_t)n;
+    W->fixed = true;
+    if (off > SCRATCH_BYTES) return fail(SDFHIP_E_STATE, "static scratch too small (%zu > %zu bytes)", off, SCRATCH_BYTES);
+    return 0;
+}
+
+// once per device, with that device current (called from sdfhip_create)
+int scratch_setup(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return 0;  // such a device gets no no-alloc entry
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ws[device]) return 0;
+    unsigned char* ptr = nullptr;
+    HIPC(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(SDFHIP_E_HIP, "hipGetSymbolAddress(scratch) returned a null pointer");
+    QueryWs* W = new QueryWs();
+    if (int rc = scratch_carve(ptr, W)) {
+        W->sorter = RadixSorter();  // (nothing of it is owned)
+        delete W;
+        return rc;
+    }
+    g_scratch_ws[device] = W;
+    return 0;
+}
 
 struct DevGuard {
     int prev = -1;
@@ -382,7 +455,7 @@ int build_topology(sdfhip_ctx* h) {
     }
     B.lo[2] = 0.f, B.inv[2] = 0.f;
     k_face_morton<<<(n + 255) / 256, 256, 0, s>>>(h->d_geo, n, B, R, h->d_codes);
-    if (int rc = h->sorter.sort(h->d_codes, h->d_sorted_face, n, 32, 1, s, nullptr, nullptr)) return rc;
+    if (int rc = h->ws.sorter.sort(h->d_codes, h->d_sorted_face, n, 32, 1, s, nullptr, nullptr)) return rc;
     HIPC(hipMemsetAsync(h->d_maxdepth, 0, sizeof(uint32_t), s));
     if (n > 1) k_lbvh_karras<<<(n - 1 + 255) / 256, 256, 0, s>>>(h->d_codes, (int)n, h->topo);
     k_lbvh_layout<<<(2 * n - 1 + 255) / 256, 256, 0, s>>>((int)n, h->topo, h->d_sorted_face,
@@ -499,7 +572,7 @@ int build_fast_tree(sdfhip_ctx* h) {
     uint32_t* sorted_idx = h->d_vidx;
     if (nv) {
         k_vtx_morton<<<(nv + 255) / 256, 256, 0, s>>>(h->d_verts, nv, B, h->d_vkeys);
-        if (int rc = h->sorter.sort(h->d_vkeys, h->d_vidx, nv, 30, 1, s, nullptr, &sorted_idx)) return rc;
+        if (int rc = h->ws.sorter.sort(h->d_vkeys, h->d_vidx, nv, 30, 1, s, nullptr, &sorted_idx)) return rc;
     }
     k_fast_positions<<<(uint32_t)((nalloc + 255) / 256), 256, 0, s>>>(h->d_verts, sorted_idx, nv,
                                                                       (uint32_t)nalloc, h->d_kd_pts4,
@@ -726,6 +799,7 @@ int launch_strict(sdfhip_ctx* h, const MeshDev& M, const float* d_pts, const uin
         const int64_t blocks = blocks_full < 4096 ? blocks_full : 4096;
         const size_t words = (size_t)blocks * QBLOCK * depth * 3;
         if (words > h->gstack_words) {
+            if (h->W->fixed) return fail(SDFHIP_E_STATE, "kd-tree deeper than %d: the no-alloc entry cannot serve this mesh", LDS_DEPTH_MAX);
             if (int rc = dalloc(&h->d_gstack, words)) return rc;
             h->gstack_words = words;
         }
@@ -746,7 +820,7 @@ struct ProfScope {  // optional hipEvent pair around everything one query call l
     hipStream_t s;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     int begin() {
-        if (h->opt_profile && h->prof_pending.size() < 8192) {
+        if (h->opt_profile && !h->W->fixed && h->prof_pending.size() < 8192) {
             if (!h->prof_free.empty()) {
                 ev = h->prof_free.back();
                 h->prof_free.pop_back();
@@ -769,21 +843,27 @@ struct ProfScope {  // optional hipEvent pair around everything one query call l
 };
 
 int reserve_query_ws(sdfhip_ctx* h, int64_t n, int64_t fb_cap) {
-    if (n > h->q_cap) {
-        if (int rc = dalloc(&h->d_qkeys, (size_t)n)) return rc;
-        if (int rc = dalloc(&h->d_qperm, (size_t)n)) return rc;
-        const size_t nw = ((size_t)n + 63) / 64 + 4;
-        if (int rc = dalloc(&h->d_amb_mask, nw)) return rc;
-        if (int rc = dalloc(&h->d_amb_cnt, nw)) return rc;
-        if (int rc = dalloc(&h->d_amb_s1, nw / 2048 + 4)) return rc;
-        if (int rc = dalloc(&h->d_amb_s2, nw / 2048 / 2048 + 4)) return rc;
-        if (!h->d_qbounds)
-            if (int rc = dalloc(&h->d_qbounds, 8)) return rc;
-        h->q_cap = n;
+    QueryWs& W = *h->W;
+    if (W.fixed) {  // the static scratch of the no-alloc entry: sized once, for SDFHIP_NOALLOC_MAX_POINTS
+        if (n > W.q_cap || fb_cap > W.fb_cap)
+            return fail(SDFHIP_E_INVALID, "batch exceeds the static scratch workspace (%lld points)", (long long)W.q_cap);
+        return 0;
     }
-    if (fb_cap > h->fb_cap) {  // [0, cap): deferred near-tie queries; [cap, 2 cap): heavy-wave queries
-        if (int rc = dalloc(&h->d_fb_list, 2 * (size_t)fb_cap)) return rc;
-        h->fb_cap = fb_cap;
+    if (n > W.q_cap) {
+        if (int rc = dalloc(&W.qkeys, (size_t)n)) return rc;
+        if (int rc = dalloc(&W.qperm, (size_t)n)) return rc;
+        const size_t nw = ((size_t)n + 63) / 64 + 4;
+        if (int rc = dalloc(&W.amb_mask, nw)) return rc;
+        if (int rc = dalloc(&W.amb_cnt, nw)) return rc;
+        if (int rc = dalloc(&W.amb_s1, nw / 2048 + 4)) return rc;
+        if (int rc = dalloc(&W.amb_s2, nw / 2048 / 2048 + 4)) return rc;
+        if (!W.qbounds)
+            if (int rc = dalloc(&W.qbounds, 8)) return rc;
+        W.q_cap = n;
+    }
+    if (fb_cap > W.fb_cap) {
+        if (int rc = dalloc(&W.fb_list, 2 * (size_t)fb_cap)) return rc;
+        W.fb_cap = fb_cap;
     }
     return 0;
 }
@@ -797,6 +877,7 @@ int reserve_query_ws(sdfhip_ctx* h, int64_t n, int64_t fb_cap) {
 template <int KIND, bool ROBUST>
 int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d_out, hipStream_t s) {
     const MeshDev M = mesh_view(h);
+    QueryWs& W = *h->W;
     const size_t osz = KIND == Q_CONTAINS ? 1 : (KIND == Q_DETAIL ? 12 : 4);
     const int64_t chunk = h->opt_chunk > 0 ? h->opt_chunk : (1 << 24);
     // Robust contains() is the ray walk only (per-lane O(1) grid lookups): sorting buys it cache
@@ -824,18 +905,18 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     if (needs_nn && M.kd_npos > 0 && n <= 0x7FFFFFFF && (double)n * (double)M.kd_npos <= scan_max) {
         if (int rc = reserve_query_ws(h, 0, n)) return rc;
         constexpr int HK = needs_nn ? KIND : Q_NN;
-        HIPC(hipMemsetAsync(h->d_fb_count, 0, 3 * sizeof(uint32_t), s));
+        HIPC(hipMemsetAsync(W.fb_count, 0, 3 * sizeof(uint32_t), s));
         const int64_t packs = (n + HEAVY_Q - 1) / HEAVY_Q;
         // kinds with a tail: positions first, then one lane per query for ray parity + face distances
-        int32_t* pos = KIND == Q_NN ? nullptr : (int32_t*)(h->d_fb_list + h->fb_cap);
+        int32_t* pos = KIND == Q_NN ? nullptr : (int32_t*)(W.fb_list + W.fb_cap);
         ProfScope prof{h, s};
         if (int rc = prof.begin()) return rc;
         if (packs <= 1024)  // few queries: 16 waves share each scan (the chain of one wave is ~0.4 ms at 190k)
             k_query_heavy<HK, ROBUST, 16><<<(uint32_t)packs, 1024, 0, s>>>(
-                M, d_pts, nullptr, nullptr, trunc, d_out, h->d_fb_list, h->d_fb_count, (uint32_t)n, pos, 0u, 0xFFFFFFFFu);
+                M, d_pts, nullptr, nullptr, trunc, d_out, W.fb_list, W.fb_count, (uint32_t)n, pos, 0u, 0xFFFFFFFFu);
         else
             k_query_heavy<HK, ROBUST, 4><<<(uint32_t)(packs < 16384 ? packs : 16384), 256, 0, s>>>(
-                M, d_pts, nullptr, nullptr, trunc, d_out, h->d_fb_list, h->d_fb_count, (uint32_t)n, pos, 0u, 0xFFFFFFFFu);
+                M, d_pts, nullptr, nullptr, trunc, d_out, W.fb_list, W.fb_count, (uint32_t)n, pos, 0u, 0xFFFFFFFFu);
         if (pos)
             k_scan_finish<HK, ROBUST><<<(uint32_t)((n + 255) / 256), 256, 0, s>>>(M, d_pts, pos, (uint32_t)n, trunc,
                                                                                  d_out);
@@ -843,13 +924,13 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         HIPC(hipGetLastError());
         if (!fast) {  // what the scan could not decide (near ties failing the path check): exact emulation
             const int64_t grid_pts = n < (int64_t)QBLOCK * 4096 ? n : (int64_t)QBLOCK * 4096;
-            if (int rc = launch_strict<KIND, ROBUST>(h, M, d_pts, h->d_fb_list, grid_pts, trunc, d_out,
-                                                     h->d_fb_count, s))
+            if (int rc = launch_strict<KIND, ROBUST>(h, M, d_pts, W.fb_list, grid_pts, trunc, d_out,
+                                                     W.fb_count, s))
                 return rc;
         }
-        if (h->opt_profile)
-            HIPC(hipMemcpyAsync(&h->last_fb, h->d_fb_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        h->last_heavy = (uint32_t)n;
+        if (h->opt_profile && !W.fixed)
+            HIPC(hipMemcpyAsync(&h->h_counts[0], W.fb_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        h->h_counts[1] = (uint32_t)n;
         return 0;
     }
     const bool packet_any =
@@ -860,7 +941,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     int64_t deferred_pts = 0;  // points whose near ties may sit in the deferred list
     int flip = 0;              // d_fb_count[flip] holds the current list length
     // d_fb_count: [0], [1] length of the deferred list (ping-pong), [2] length of the heavy list
-    if (packet_any) HIPC(hipMemsetAsync(h->d_fb_count, 0, 3 * sizeof(uint32_t), s));
+    if (packet_any) HIPC(hipMemsetAsync(W.fb_count, 0, 3 * sizeof(uint32_t), s));
     auto flush = [&]() -> int {
         if (deferred_pts == 0) return 0;
         constexpr int HK = (KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST)) ? Q_NN : KIND;
@@ -876,25 +957,25 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             constexpr uint32_t HEAVY_SHORT = 8192;
             const int64_t g16 = packs < HEAVY_SHORT / HEAVY_Q ? packs : HEAVY_SHORT / HEAVY_Q;
             k_query_heavy<HK, ROBUST, 16><<<(uint32_t)g16, 1024, 0, s>>>(
-                M, d_pts, h->d_fb_list + h->fb_cap, h->d_fb_count + 2, trunc, d_out, h->d_fb_list,
-                h->d_fb_count + flip, 0u, nullptr, 1u, HEAVY_SHORT);
+                M, d_pts, W.fb_list + W.fb_cap, W.fb_count + 2, trunc, d_out, W.fb_list,
+                W.fb_count + flip, 0u, nullptr, 1u, HEAVY_SHORT);
             if (deferred_pts > (int64_t)HEAVY_SHORT)
                 k_query_heavy<HK, ROBUST, 4><<<(uint32_t)(packs < 8192 ? packs : 8192), 256, 0, s>>>(
-                    M, d_pts, h->d_fb_list + h->fb_cap, h->d_fb_count + 2, trunc, d_out, h->d_fb_list,
-                    h->d_fb_count + flip, 0u, nullptr, HEAVY_SHORT + 1u, 0xFFFFFFFFu);
+                    M, d_pts, W.fb_list + W.fb_cap, W.fb_count + 2, trunc, d_out, W.fb_list,
+                    W.fb_count + flip, 0u, nullptr, HEAVY_SHORT + 1u, 0xFFFFFFFFu);
             HIPC(hipGetLastError());
         }
         if (!fast) {
             const int64_t grid_pts = deferred_pts < (int64_t)QBLOCK * 4096 ? deferred_pts : (int64_t)QBLOCK * 4096;
-            if (int rc = launch_strict<KIND, ROBUST>(h, M, d_pts, h->d_fb_list, grid_pts, trunc, d_out,
-                                                     h->d_fb_count + flip, s))
+            if (int rc = launch_strict<KIND, ROBUST>(h, M, d_pts, W.fb_list, grid_pts, trunc, d_out,
+                                                     W.fb_count + flip, s))
                 return rc;
         }
-        if (h->opt_profile) {
-            HIPC(hipMemcpyAsync(&h->last_fb, h->d_fb_count + flip, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIPC(hipMemcpyAsync(&h->last_heavy, h->d_fb_count + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (h->opt_profile && !W.fixed) {
+            HIPC(hipMemcpyAsync(&h->h_counts[0], W.fb_count + flip, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPC(hipMemcpyAsync(&h->h_counts[1], W.fb_count + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         }
-        HIPC(hipMemsetAsync(h->d_fb_count, 0, 3 * sizeof(uint32_t), s));
+        HIPC(hipMemsetAsync(W.fb_count, 0, 3 * sizeof(uint32_t), s));
         flip = 0;
         deferred_pts = 0;
         return 0;
@@ -905,21 +986,21 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         void* o = (char*)d_out + osz * (size_t)off;
         const uint32_t* perm = nullptr;
         if (h->opt_sort && m >= sort_min) {
-            k_bounds_init<<<1, 64, 0, s>>>(h->d_qbounds);
+            k_bounds_init<<<1, 64, 0, s>>>(W.qbounds);
             // large batches: the bounds come from a strided sample (1/16 of the points, in 3 KB runs)
             const int sample = m >= (8 << 20) ? 16 : 1;
             const int64_t groups = m / 4 / sample;
             const int nb = (int)((groups + 255) / 256 < 1024 ? (groups + 255) / 256 + 1 : 1024);
-            k_bounds<<<nb, 256, 0, s>>>(p, m, h->d_qbounds, sample);
-            k_query_morton<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(p, (uint32_t)m, h->d_qbounds,
-                                                                       h->d_qkeys);
+            k_bounds<<<nb, 256, 0, s>>>(p, m, W.qbounds, sample);
+            k_query_morton<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(p, (uint32_t)m, W.qbounds,
+                                                                       W.qkeys);
             uint32_t* sorted_perm = nullptr;
-            if (int rc = h->sorter.sort(h->d_qkeys, h->d_qperm, (uint32_t)m, 24, 1, s, nullptr, &sorted_perm, false))
+            if (int rc = W.sorter.sort(W.qkeys, W.qperm, (uint32_t)m, 24, 1, s, nullptr, &sorted_perm, false))
                 return rc;
             perm = sorted_perm;
         }
         if (packet_any && (perm || fast)) {
-            if (deferred_pts + m > h->fb_cap)
+            if (deferred_pts + m > W.fb_cap)
                 if (int rc = flush()) return rc;
             constexpr int PK = KIND == Q_DETAIL ? Q_NN : KIND;
             ProfScope prof{h, s};  // the dominant kernel, one event pair per launch
@@ -928,22 +1009,22 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             // tree of fast_nn has no strict kernel behind it and keeps the exact walk
             if (!fast && (h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0))
                 k_query_packet<PK, ROBUST, true><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, 0, s>>>(
-                    M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, (uint32_t)off,
-                    h->d_fb_list + h->fb_cap, h->d_fb_count + 2);
+                    M, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
+                    W.fb_list + W.fb_cap, W.fb_count + 2);
             else
                 k_query_packet<PK, ROBUST, false><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, 0, s>>>(
-                    M, p, perm, m, trunc, o, h->d_amb_mask, h->d_amb_cnt, (uint32_t)off,
-                    h->d_fb_list + h->fb_cap, h->d_fb_count + 2);
+                    M, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
+                    W.fb_list + W.fb_cap, W.fb_count + 2);
             if (int rc = prof.end(m)) return rc;
             if (fast) {  // no near-tie deferral in this mode, only the heavy list
                 HIPC(hipGetLastError());
                 deferred_pts += m;
                 continue;
             }
-            exclusive_scan_u32(h->d_amb_cnt, (uint32_t)((m + 63) / 64), h->d_amb_s1, h->d_amb_s2, s);
+            exclusive_scan_u32(W.amb_cnt, (uint32_t)((m + 63) / 64), W.amb_s1, W.amb_s2, s);
             k_fb_compact<<<(uint32_t)(((m + 63) / 64 + 255) / 256), 256, 0, s>>>(
-                h->d_amb_mask, h->d_amb_cnt, perm, m, (uint32_t)off, h->d_fb_list, h->d_fb_count + flip,
-                h->d_fb_count + (flip ^ 1));
+                W.amb_mask, W.amb_cnt, perm, m, (uint32_t)off, W.fb_list, W.fb_count + flip,
+                W.fb_count + (flip ^ 1));
             HIPC(hipGetLastError());
             flip ^= 1;
             deferred_pts += m;
@@ -1256,9 +1337,15 @@ static int create_impl(const float* verts, uint32_t nv, const uint32_t* faces, u
     auto A = [&](int r) { if (!rc) rc = r; };
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(SDFHIP_E_HIP, "hipStreamCreate failed");
+    A(scratch_setup(device));  // this device's address of the static scratch (no-alloc entry)
+    if (!rc && hipEventCreateWithFlags(&h->ev_query, hipEventDisableTiming) != hipSuccess)
+        rc = fail(SDFHIP_E_HIP, "hipEventCreate failed");
+    if (!rc && hipHostMalloc((void**)&h->h_counts, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+        rc = fail(SDFHIP_E_NOMEM, "hipHostMalloc failed");
+    if (!rc) h->h_counts[0] = h->h_counts[1] = 0;
     A(dalloc(&h->d_verts, 3 * (size_t)nv));
     A(dalloc(&h->d_faces, 3 * (size_t)nf));
-    A(dalloc(&h->d_fb_count, 4));
+    A(dalloc(&h->ws.fb_count, 4));
     A(dalloc(&h->d_adj_off, (size_t)nv + 1));
     A(dalloc(&h->d_adj_faces, 3 * (size_t)nf));
     A(dalloc(&h->d_geo, 4 * (size_t)nf));
@@ -1317,12 +1404,13 @@ void sdfhip_destroy(sdfhip_t* h) {
                     h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
-                    h->topo.depthI, h->d_qkeys, h->d_qperm, h->d_qbounds, h->d_gstack, h->d_kd_pts4,
-                    h->d_fb_list, h->d_fb_count, h->d_amb_mask, h->d_amb_cnt, h->d_amb_s1, h->d_amb_s2,
+                    h->topo.depthI, h->ws.qkeys, h->ws.qperm, h->ws.qbounds, h->d_gstack, h->d_kd_pts4,
+                    h->ws.fb_list, h->ws.fb_count, h->ws.amb_mask, h->ws.amb_cnt, h->ws.amb_s1, h->ws.amb_s2,
                     h->d_vkeys, h->d_vidx};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    h->sorter.release();
+    h->ws.sorter.release();
+    if (h->h_counts) (void)hipHostFree(h->h_counts);
     h->grid.release();
     for (int k = 0; k < 2; ++k) {
         if (h->d_stage_in[k]) (void)hipFree(h->d_stage_in[k]);
@@ -1388,6 +1476,30 @@ int sdfhip_sdf(sdfhip_t* h, const float* p, int64_t n, int trunc, float* out) {
 }
 int sdfhip_sdf_device(sdfhip_t* h, const float* p, int64_t n, int trunc, float* out, void* s) {
     return guarded([&]() -> int { return run_query_dev(h, Q_SDF, p, n, trunc, out, s); });
+}
+int sdfhip_sdf_device_noalloc(sdfhip_t* h, const float* p, int64_t n, int trunc, float* out, void* stream) {
+    if (!h) return fail(SDFHIP_E_INVALID, "null handle");
+    if (n > NOALLOC_MAX_POINTS)
+        return fail(SDFHIP_E_INVALID, "sdfhip_sdf_device_noalloc takes at most %lld points per call (got %lld)",
+                    (long long)NOALLOC_MAX_POINTS, (long long)n);
+    return guarded([&]() -> int {
+        std::lock_guard<std::mutex> lk(h->mu);
+        DevGuard g(h->device);
+        if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
+        QueryWs* W = nullptr;
+        if (h->device >= 0 && h->device < MAX_DEVICES) {
+            std::lock_guard<std::mutex> ls(g_scratch_mu);
+            W = g_scratch_ws[h->device];
+        }
+        if (!W) return fail(SDFHIP_E_STATE, "no static scratch on device %d", h->device);
+        if (int rc = wait_for_queries(h, (hipStream_t)stream)) return rc;
+        h->W = W;  // every buffer of this call comes out of the static scratch; nothing is allocated
+        const int rc = run_query(h, Q_SDF, p, n, trunc, out, (hipStream_t)stream);
+        h->W = &h->ws;
+        if (n > 0)
+            if (int rc2 = mark_query(h, (hipStream_t)stream)) return rc ? rc : rc2;
+        return rc;
+    });
 }
 int sdfhip_contains(sdfhip_t* h, const float* p, int64_t n, uint8_t* out) {
     return guarded([&]() -> int { return run_query_host(h, Q_CONTAINS, p, n, 0, out); });
@@ -1491,10 +1603,12 @@ int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* o) {
     o->query_kernel_points = h->prof_points;
     o->last_fallback_points = 0;
     o->last_heavy_points = 0;
-    if (h->d_fb_count) {
+    if (h->h_counts) {
+        // the counters arrive by an asynchronous copy on the query's stream: wait for that query
         DevGuard g(h->device);
-        o->last_fallback_points = h->last_fb;
-        o->last_heavy_points = h->last_heavy;
+        if (h->query_pending && h->ev_query) (void)hipEventSynchronize(h->ev_query);
+        o->last_fallback_points = h->h_counts[0];
+        o->last_heavy_points = h->h_counts[1];
     }
     return 0;
 }

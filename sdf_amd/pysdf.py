@@ -47,7 +47,7 @@ _lib = None
 # every symbol include/sdfhip.h declares (tests check that the library exports them all)
 ABI_SYMBOLS = [
     "sdfhip_create", "sdfhip_destroy", "sdfhip_update", "sdfhip_update_from_device",
-    "sdfhip_set_raycast_axes", "sdfhip_get_raycast_axes", "sdfhip_sdf", "sdfhip_sdf_device",
+    "sdfhip_set_raycast_axes", "sdfhip_get_raycast_axes", "sdfhip_sdf", "sdfhip_sdf_device", "sdfhip_sdf_device_noalloc",
     "sdfhip_contains", "sdfhip_contains_device", "sdfhip_nn", "sdfhip_nn_device",
     "sdfhip_raycast_detail", "sdfhip_robust", "sdfhip_own_data", "sdfhip_device",
     "sdfhip_num_verts", "sdfhip_num_faces", "sdfhip_verts", "sdfhip_faces",
@@ -95,6 +95,7 @@ def load_library():
     L.sdfhip_get_raycast_axes.argtypes = [vp, _fp]
     L.sdfhip_sdf.argtypes = [vp, _fp, C.c_int64, C.c_int, _fp]
     L.sdfhip_sdf_device.argtypes = [vp, vp, C.c_int64, C.c_int, vp, vp]
+    L.sdfhip_sdf_device_noalloc.argtypes = [vp, vp, C.c_int64, C.c_int, vp, vp]
     L.sdfhip_contains.argtypes = [vp, _fp, C.c_int64, _bp]
     L.sdfhip_contains_device.argtypes = [vp, vp, C.c_int64, vp, vp]
     L.sdfhip_nn.argtypes = [vp, _fp, C.c_int64, _ip]
