@@ -29,6 +29,13 @@
 // the query is "ambiguous" and is appended to a fallback list that the strict per-lane
 // kernel (kd_nearest: exact emulation) processes afterwards.  Parity is by construction.
 // =========================================================================================
+#ifdef SDFK_NO_NT
+#define SDFK_NT_LOAD(P) (*(P))
+#define SDFK_NT_STORE(V, P) (*(P) = (V))
+#else
+#define SDFK_NT_LOAD(P) __builtin_nontemporal_load(P)
+#define SDFK_NT_STORE(V, P) __builtin_nontemporal_store((V), (P))
+#endif
 #ifndef SDFK_CHUNK_BATCH
 #define SDFK_CHUNK_BATCH 3
 #endif
@@ -195,7 +202,7 @@ struct ObbLane {
 template <bool PLANE>
 __device__ __forceinline__ ObbLane obb_wide(const float4* __restrict__ rec, uint32_t lane, float cx, float cy,
                                             float cz, float Ew, float gx = 0.f, float gy = 0.f, float gz = 0.f,
-                                            float rho = 0.f) {
+                                            float hx = 0.f, float hy = 0.f, float hz = 0.f) {
     const float4 A = rec[lane], B = rec[64u + lane], C = rec[128u + lane], D = rec[192u + lane];
     const float dx = cx - A.x, dy = cy - A.y, dz = cz - A.z;
     const float p0 = __builtin_fmaf(B.x, dx, __builtin_fmaf(B.y, dy, B.z * dz));
@@ -222,9 +229,8 @@ __device__ __forceinline__ ObbLane obb_wide(const float4* __restrict__ rec, uint
         const float sup = __builtin_fmaf(A.w, fabsf(m0), __builtin_fmaf(B.w, fabsf(m1), C.w * fabsf(m2)));
         o.f0 = __builtin_fmaf(o.nx, dx, __builtin_fmaf(o.ny, dy, o.nz * dz)) - (sup + 4.f * Ew);
         // for every lane l:  f0 + n.e_l - rr_l  =  f0 + (n - g).e_l - (rr_l - g.e_l)  >=  pk - max_l (rr_l - g.e_l)
-        const float ux = o.nx - gx, uy = o.ny - gy, uz = o.nz - gz;
-        const float dn = __builtin_amdgcn_sqrtf(__builtin_fmaf(ux, ux, __builtin_fmaf(uy, uy, uz * uz)));
-        o.pk = o.f0 - __builtin_fmaf(dn, 1.f + PK_EPS, PK_EPS) * rho;
+        // with |(n - g).e_l| <= sum_i |n_i - g_i| h_i, h = half extents of the queries' bounding box (rounded up)
+        o.pk = o.f0 - __builtin_fmaf(fabsf(o.nx - gx), hx, __builtin_fmaf(fabsf(o.ny - gy), hy, fabsf(o.nz - gz) * hz));
     }
     return o;
 }
@@ -392,8 +398,11 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
     const float cy = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(qy))) + pk_ord2f(wave_umax(pk_f2ord(qy))));
     const float cz = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(qz))) + pk_ord2f(wave_umax(pk_f2ord(qz))));
     const float ex = qx - cx, ey = qy - cy, ez = qz - cz;
-    const float e2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
-    const float rho = __builtin_amdgcn_sqrtf(__uint_as_float(wave_umax(__float_as_uint(e2)))) * (1.f + PK_EPS);
+    // half extents of the queries' box around c (>= |e| of every lane, with a margin for the dot products)
+    const float hx = __uint_as_float(wave_umax(__float_as_uint(fabsf(ex)))) * (1.f + 4.f * PK_EPS);
+    const float hy = __uint_as_float(wave_umax(__float_as_uint(fabsf(ey)))) * (1.f + 4.f * PK_EPS);
+    const float hz = __uint_as_float(wave_umax(__float_as_uint(fabsf(ez)))) * (1.f + 4.f * PK_EPS);
+    const float rho = __builtin_amdgcn_sqrtf(__builtin_fmaf(hx, hx, __builtin_fmaf(hy, hy, hz * hz))) * (1.f + PK_EPS);
     // absolute slack of the box tests: 64u x (an upper bound of |c - centre of any box|)
     const float reach = ((fabsf(cx - M.obb_cm[0]) + fabsf(cy - M.obb_cm[1])) + fabsf(cz - M.obb_cm[2])) + (M.obb_rm + rho);
     const float Ew = 3.8146973e-6f * reach;
@@ -405,18 +414,22 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
         const float thr_ = APPROX ? fmaxf(SA.B1 + Qe, 0.f) * cm : __uint_as_float(SE.b) * c2;       \
         rr = __builtin_fmaf(__builtin_amdgcn_sqrtf(thr_), 1.f + PK_EPS, PK_EPS * rho);              \
     }
-#define SDFK_PK_EVAL(REF)                                 \
-    {                                                     \
-        SDFK_COUNT(2, 1);                                 \
-        SDFK_COUNT(3, (REF) & 15u);                       \
-        work += (REF) & 15u;                              \
-        if (APPROX)                                       \
-            group_approx(M, X2, Y2, Z2, (REF), SA);       \
-        else                                              \
-            group_exact(M, qx, qy, qz, (REF), SE);        \
-        SDFK_PK_REFRESH()                                 \
+    // (the thresholds only move when some lane's minimum did: most groups past the first few change nothing)
+#define SDFK_PK_EVAL(REF)                                                                 \
+    {                                                                                     \
+        SDFK_COUNT(2, 1);                                                                 \
+        SDFK_COUNT(3, (REF) & 15u);                                                       \
+        work += (REF) & 15u;                                                              \
+        const uint32_t old_ = APPROX ? __float_as_uint(SA.B1) : SE.b;                     \
+        if (APPROX)                                                                       \
+            group_approx(M, X2, Y2, Z2, (REF), SA);                                       \
+        else                                                                              \
+            group_exact(M, qx, qy, qz, (REF), SE);                                        \
+        moved = __ballot(old_ != (APPROX ? __float_as_uint(SA.B1) : SE.b)) != 0ull;       \
+        if (moved) SDFK_PK_REFRESH()                                                      \
     }
     uint32_t work = 0;  // chunks evaluated + candidates tested so far (wave-uniform)
+    bool moved = false;
     const uint32_t nrows = (M.kd_nl1 + 63u) >> 6;
     // ---- greedy descent: the nearest L1 node, its nearest group; evaluating it gives every lane a bound
     uint32_t j0, g0;
@@ -462,7 +475,7 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
     // Children are taken nearest first (by their packet-level bound): the thresholds are final after
     // the first few groups, and once the nearest remaining child fails the packet-level test all do.
     for (uint32_t row = 0; row < nrows; ++row) {
-        const ObbLane o1 = obb_wide<true>(M.kd_l1obb + 256u * (size_t)row, lane, cx, cy, cz, Ew, gx, gy, gz, rho);
+        const ObbLane o1 = obb_wide<true>(M.kd_l1obb + 256u * (size_t)row, lane, cx, cy, cz, Ew, gx, gy, gz, hx, hy, hz);
         SDFK_COUNT(1, 1);
         float res = SDFK_PK_RES();
         bool alive1 = 64u * row + lane < M.kd_nl1 && !(o1.pk > res);
@@ -483,7 +496,7 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
             }
             const uint32_t j = 64u * row + k;
             const uint32_t cnt = min(64u, M.kd_ngroups - 64u * j);
-            const ObbLane o = obb_wide<true>(M.kd_gobb + 256u * (size_t)j, lane, cx, cy, cz, Ew, gx, gy, gz, rho);
+            const ObbLane o = obb_wide<true>(M.kd_gobb + 256u * (size_t)j, lane, cx, cy, cz, Ew, gx, gy, gz, hx, hy, hz);
             SDFK_COUNT(1, 1);
             bool alive = lane < cnt && !(o.pk > res) && !(j == j0 && lane == g0);  // (g0: evaluated by the greedy descent)
             unsigned long long m2 = __ballot(alive);
@@ -509,7 +522,7 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
                 const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)o.tag, (int)g);
                 SDFK_PK_EVAL(ref)
                 if (work > M.heavy_budget) return true;  // give up (wave-uniform): k_query_heavy takes over
-                res = SDFK_PK_RES();  // tightened
+                if (moved) res = SDFK_PK_RES();  // tightened
             }
         }
     }
@@ -619,8 +632,9 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
     // lanes past the end of the batch repeat its last query (and write nothing): they then ask
     // for no subtree a real lane does not
     const int64_t ic = valid ? i : n - 1;
-    const int64_t src = perm ? (int64_t)perm[ic] : ic;
-    const V3 p = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
+    // the point stream (and the results) pass through once: non-temporal, so that L2 keeps the trees
+    const int64_t src = perm ? (int64_t)SDFK_NT_LOAD(&perm[ic]) : ic;
+    const V3 p = {SDFK_NT_LOAD(&pts[3 * src]), SDFK_NT_LOAD(&pts[3 * src + 1]), SDFK_NT_LOAD(&pts[3 * src + 2])};
     float sign = 0.f;
     if (ROBUST && KIND != Q_NN) sign = raycast_packet(M, p, valid);  // sdf.cpp:110
     if (ROBUST && KIND == Q_CONTAINS) {  // sdf.cpp:163-169: no nearest-vertex search at all
@@ -722,14 +736,14 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
     }
     if (!valid || amb) return;
     if (KIND == Q_NN) {
-        ((int32_t*)out)[src] = pos >= 0 ? M.kd_vind[pos] : -1;  // (-1: fast mode, no finite distance)
+        SDFK_NT_STORE(pos >= 0 ? M.kd_vind[pos] : -1, &((int32_t*)out)[src]);  // (-1: fast mode, no finite distance)
     } else {
         const bool trunc = (KIND == Q_CONTAINS) ? true : (trunc_aabb != 0);
         const float v = calc_tail<ROBUST>(M, p, trunc, sign, pos);
         if (KIND == Q_CONTAINS)
             ((uint8_t*)out)[src] = v >= 0;
         else
-            ((float*)out)[src] = v;
+            SDFK_NT_STORE(v, &((float*)out)[src]);
     }
 }
 
