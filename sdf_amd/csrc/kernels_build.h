@@ -70,8 +70,10 @@ __global__ void k_bounds_init(uint32_t* b) {
     if (threadIdx.x < 3) b[threadIdx.x] = 0xFFFFFFFFu;
     else if (threadIdx.x < 6) b[threadIdx.x] = 0u;
 }
-// flat float view of the [n,3] points: thread-contiguous float4 loads (coordinate = index % 3);
-// base pointers from hipMalloc / torch are 16-byte aligned, the tail is read scalar
+// flat float view of the [n,3] points: thread-contiguous float4 loads (coordinate = index % 3).
+// Base pointers from hipMalloc / torch are 16-byte aligned, but a slice (pts[1:], a shard that starts
+// at an odd point) is not: the float4 view then starts at the first aligned float (`head` floats in),
+// and the coordinates are rotated back at the end.  Head and tail are read scalar.
 // sample > 1: only one run of 64 groups (256 points, 3 KB) in every `sample` runs is read.  The
 // bounds only scale the Morton codes of the query sort (values outside are clamped into the border
 // cells), so a sample costs at most a little coherence, never a result.
@@ -79,10 +81,11 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, i
                                                 int sample) {
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     const int64_t nf = 3 * n;
-    const bool aligned = (((uintptr_t)pts) & 15) == 0;
-    const int64_t ngroups = aligned ? nf / 12 : 0;  // 12 floats = 4 points = 3 float4
+    const int mis = (int)((((uintptr_t)pts) & 15) >> 2);  // floats past a 16-byte boundary
+    const int64_t head = mis ? (4 - mis < nf ? 4 - mis : nf) : 0;
+    const int64_t ngroups = (nf - head) / 12;  // 12 floats = 4 points = 3 float4
     const int64_t nsampled = sample > 1 ? (ngroups / (64 * (int64_t)sample)) * 64 : ngroups;
-    const float4* p4 = (const float4*)pts;
+    const float4* p4 = (const float4*)(pts + head);
     for (int64_t gs = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gs < nsampled;
          gs += (int64_t)gridDim.x * blockDim.x) {
         const int64_t g = sample > 1 ? (gs >> 6) * 64 * sample + (gs & 63) : gs;
@@ -97,8 +100,19 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, i
             }
         }
     }
-    for (int64_t i = 12 * ngroups + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf && sample <= 1;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    if (head % 3 == 1) {  // float k of the aligned view is coordinate (k + head) % 3 of its point
+        const float l2 = lo[2], h2 = hi[2];
+        lo[2] = lo[1], hi[2] = hi[1], lo[1] = lo[0], hi[1] = hi[0], lo[0] = l2, hi[0] = h2;
+    } else if (head % 3 == 2) {
+        const float l0 = lo[0], h0 = hi[0];
+        lo[0] = lo[1], hi[0] = hi[1], lo[1] = lo[2], hi[1] = hi[2], lo[2] = l0, hi[2] = h0;
+    }
+    // head and tail, scalar (a sampled pass may skip them: the bounds are a sample anyway — but a
+    // batch too short for one sampled run is read completely)
+    const bool edges = sample <= 1 || nsampled == 0;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; edges && j < nf - 12 * ngroups;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = j < head ? j : 12 * ngroups + j;
         const float x = pts[i];
         const int d = (int)(i % 3);
         if (fabsf(x) <= FLT_MAX) {

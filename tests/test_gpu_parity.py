@@ -343,6 +343,32 @@ def test_sampled_query_bounds_with_outliers():
     assert (nn[sub].cpu().numpy() == o.nn(h)).all()
 
 
+@pytest.mark.parametrize("start", [1, 2, 3])
+def test_unaligned_device_points_keep_the_query_sort_coherent(start):
+    """A slice such as pts[1:] (or a shard that starts at an odd point) is not 16-byte aligned.  The sampled
+    bounds of the query sort must still see it: with empty bounds every Morton key is 0, the sort is the
+    identity and nearly every query ends in the brute-force scan (correct, but seconds instead of ms)."""
+    import torch
+    v, f = meshes.torus(83, 83)
+    s = SDF(v, f)
+    s.set_raycast_axes(meshes.random_rotation(8))
+    s.set_option("profile", 1)  # the heavy-list length is read back only while profiling
+    n = 8_500_000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = torch.rand((n + 4, 3), device="cuda", generator=g) * 2 - 1
+    sl = base[start:start + n]
+    assert sl.data_ptr() % 16 != 0 and sl.is_contiguous()
+    al = sl.clone()
+    assert al.data_ptr() % 16 == 0
+    for fn in (s.nn, s.__call__):
+        a = fn(al)
+        heavy_al = s.stats["last_heavy_points"]
+        b = fn(sl)
+        heavy_sl = s.stats["last_heavy_points"]
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        assert heavy_sl <= max(2 * heavy_al, n // 1000), (heavy_al, heavy_sl)
+
+
 def test_large_mesh_properties_full_size():
     """BASELINE config-4 scale mesh: size-independent properties + a sampled oracle check."""
     v, f = meshes.torus(424, 424)
