@@ -59,7 +59,21 @@ struct SDF {
         bool copy = false)
         : SDF(verts.data(), (uint32_t)verts.rows(), faces.data(), (uint32_t)faces.rows(), robust, copy) {}
 #endif
-    ~SDF() { sdfhip_destroy(h_); }
+    // several GPUs of this process (no counterpart: the reference is one CPU process): the host-array
+    // queries are cut into contiguous ranges, one per listed device (sdfhip_group_*)
+    SDF(const float* verts, uint32_t n_verts, const Index* faces, uint32_t n_faces, bool robust, bool copy,
+        const std::vector<int>& devices)
+        : robust(robust), own_data(copy) {
+        check(sdfhip_group_create(verts, n_verts, faces, n_faces, robust ? 1 : 0, copy ? 1 : 0, devices.data(),
+                                  (int)devices.size(), &g_));
+        h_ = sdfhip_group_member(g_, 0);  // accessors (verts_mutable, aabb, ...) go to member 0
+    }
+    ~SDF() {
+        if (g_)
+            sdfhip_group_destroy(g_);
+        else
+            sdfhip_destroy(h_);
+    }
     static uint64_t fresh_seed() {
         std::random_device rd;
         return ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^
@@ -72,17 +86,18 @@ struct SDF {
     std::vector<float> operator()(const float* points, int64_t n, bool trunc_aabb = false,
                                   int /*n_threads*/ = 0) const {
         std::vector<float> out((size_t)n);
-        check(sdfhip_sdf(h_, points, n, trunc_aabb ? 1 : 0, out.data()));
+        check(g_ ? sdfhip_group_sdf(g_, points, n, trunc_aabb ? 1 : 0, out.data())
+                 : sdfhip_sdf(h_, points, n, trunc_aabb ? 1 : 0, out.data()));
         return out;
     }
     std::vector<int> nn(const float* points, int64_t n, int /*n_threads*/ = 0) const {
         std::vector<int> out((size_t)n);
-        check(sdfhip_nn(h_, points, n, out.data()));
+        check(g_ ? sdfhip_group_nn(g_, points, n, out.data()) : sdfhip_nn(h_, points, n, out.data()));
         return out;
     }
     std::vector<uint8_t> contains(const float* points, int64_t n, int /*n_threads*/ = 0) const {
         std::vector<uint8_t> out((size_t)n);
-        check(sdfhip_contains(h_, points, n, out.data()));
+        check(g_ ? sdfhip_group_contains(g_, points, n, out.data()) : sdfhip_contains(h_, points, n, out.data()));
         return out;
     }
     // device-resident points / results on `stream` (hipStream_t), asynchronous
@@ -117,7 +132,7 @@ struct SDF {
     }
 #endif
     // sdf.hpp:206-208 / sdf.cpp:391
-    void update() { check(sdfhip_update(h_)); }
+    void update() { check(g_ ? sdfhip_group_update(g_) : sdfhip_update(h_)); }
 
     // sdf.hpp:210-213 / sdf.cpp:176-234.  `seed` (extension) makes the samples reproducible;
     // by default a fresh one is drawn, like the reference's time-seeded generator.
@@ -219,6 +234,7 @@ struct SDF {
         if (rc != 0) throw std::runtime_error(std::string("sdfhip: ") + sdfhip_last_error());
     }
     sdfhip_t* h_ = nullptr;
+    sdfhip_group_t* g_ = nullptr;  // set when the object spans several GPUs (then h_ = member 0)
 };
 
 // sdf::Renderer (sdf.hpp:282-369 of the reference, src/renderer.cpp): image-space raycaster.

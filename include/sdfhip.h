@@ -73,7 +73,8 @@ int sdfhip_update_from_device(sdfhip_t* h, const float* d_verts, void* stream);
 /* The reference's rotation is private and non-deterministic (sdf.cpp:271, util.cpp:32-40),
  * so parity is only defined "given the same R".  set: pins R (row-major 3x3, used as
  * `p * R`, sdf.cpp:284-285) for this and all later updates and re-runs the rotation-
- * dependent part of update().  pin = 0 un-pins (later updates draw a fresh R). */
+ * dependent part of update().  pin = 2 pins R without that re-run: it takes effect at the next
+ * sdfhip_update.  pin = 0 un-pins (later updates draw a fresh R). */
 int sdfhip_set_raycast_axes(sdfhip_t* h, const float R[9], int pin);
 int sdfhip_get_raycast_axes(const sdfhip_t* h, float R[9]);
 
@@ -148,6 +149,30 @@ int sdfhip_adj_faces(const sdfhip_t* h, uint32_t vert, const int32_t** ids);
  * the reference's message. */
 int sdfhip_sample_surface(sdfhip_t* h, int64_t n, uint64_t seed, float* out);
 int sdfhip_sample_surface_device(sdfhip_t* h, int64_t n, uint64_t seed, float* d_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One sdf::SDF on several GPUs of one process (no counterpart: the reference is CPU-only, its
+ * parallelism is maybe_parallel_for over point indices, util.cpp:7-29).  A group holds one handle per
+ * listed device (an ordinal may repeat), all built from the same host arrays and the same ray-cast
+ * rotation.  The host-pointer queries below replace SDF::operator() / contains / nn like their
+ * single-handle namesakes: the N points are cut into contiguous ranges [r * ceil(N/G), ...), member r
+ * evaluates its range on its own GPU (own host thread, staging buffers, stream and PCIe link) and
+ * writes into the same range of `out`.  There is no data-path collective.  copy = 1: member 0 owns
+ * the host copy (sdfhip_verts_mutable(sdfhip_group_member(g, 0))), the others read it.
+ * sdfhip_group_update replaces SDF::update(): member 0 draws the new rotation (unless pinned through
+ * sdfhip_group_set_raycast_axes), every member then re-reads the vertices and rebuilds concurrently. */
+typedef struct sdfhip_group sdfhip_group_t;
+int sdfhip_group_create(const float* verts, uint32_t n_verts, const uint32_t* faces, uint32_t n_faces,
+                        int robust, int copy, const int* devices, int n_devices, sdfhip_group_t** out);
+void sdfhip_group_destroy(sdfhip_group_t* g);
+int sdfhip_group_size(const sdfhip_group_t* g);
+sdfhip_t* sdfhip_group_member(sdfhip_group_t* g, int k);
+int sdfhip_group_update(sdfhip_group_t* g);
+int sdfhip_group_set_raycast_axes(sdfhip_group_t* g, const float R[9], int pin);
+int sdfhip_group_get_raycast_axes(const sdfhip_group_t* g, float R[9]);
+int sdfhip_group_sdf(sdfhip_group_t* g, const float* points, int64_t n, int trunc_aabb, float* out);
+int sdfhip_group_contains(sdfhip_group_t* g, const float* points, int64_t n, uint8_t* out);
+int sdfhip_group_nn(sdfhip_group_t* g, const float* points, int64_t n, int32_t* out);
 
 /* Statistics of the structures behind the handle (no counterpart in the reference). */
 typedef struct {

@@ -1457,7 +1457,7 @@ int sdfhip_set_raycast_axes(sdfhip_t* h, const float R[9], int pin) {
     if (!R) return fail(SDFHIP_E_INVALID, "null R");
     std::memcpy(h->R, R, 9 * sizeof(float));
     h->R_pinned = true;
-    if (!h->robust) return 0;
+    if (!h->robust || pin == 2) return 0;  // (2: stored now, applied by the next sdfhip_update)
     DevGuard g(h->device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
     if (int rc = wait_for_queries(h, h->stream)) return rc;
@@ -1718,3 +1718,5 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
 }  // extern "C"
 
 #include "renderer.h"
+
+#include "group.h"

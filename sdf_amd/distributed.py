@@ -66,7 +66,14 @@ class ShardedSDF:
                  engine_factory=None):
         import torch.distributed as dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        bdev = "cpu" if dist.get_backend() == "gloo" else f"cuda:{device if device is not None else 0}"
+        if dist.get_backend() == "gloo":
+            bdev = "cpu"
+        else:  # one process per GPU: broadcast through, and build on, THIS rank's device
+            import torch
+            if device is None:
+                device = torch.cuda.current_device()
+            bdev = f"cuda:{int(device)}"
+        self._bdev, self._src, self.robust = bdev, src, bool(robust)
         if robust and R is None and self.rank == src:
             from .meshes import random_rotation
             R = random_rotation(int(np.random.SeedSequence().entropy % (2 ** 31)))
@@ -78,6 +85,35 @@ class ShardedSDF:
             self.engine = engine_factory(self.verts, self.faces, robust)
         if robust and self.R is not None and hasattr(self.engine, "set_raycast_axes"):
             self.engine.set_raycast_axes(self.R)
+
+    def update(self, verts=None, R=None):
+        """SDF::update() across the ranks (sdf.cpp:391, 31-73; the deforming-mesh loop of demo.cpp:109-121):
+        rank `src` passes the new vertex positions (None: unchanged) and, for a robust mesh, optionally a
+        rotation; by default it draws a fresh one, as the reference's update() does.  Both are broadcast,
+        every rank writes the vertices into its engine (`vertices_mutable`) and rebuilds with the SAME R."""
+        import torch
+        import torch.distributed as dist
+        hdr = torch.zeros(2, dtype=torch.int64, device=self._bdev)
+        if self.rank == self._src:
+            if self.robust and R is None:
+                from .meshes import random_rotation
+                R = random_rotation(int(np.random.SeedSequence().entropy % (2 ** 31)))
+            hdr[0], hdr[1] = 0 if verts is None else 1, 1 if self.robust else 0
+        dist.broadcast(hdr, self._src)
+        has_v, has_r = (int(x) for x in hdr.cpu())
+        if has_v:
+            if self.rank == self._src and np.asarray(verts).shape != self.verts.shape:
+                raise ValueError("update() cannot change the number of vertices")
+            self.verts = _bcast_array(verts, (self.verts.shape, np.float32), self._src, dist, self._bdev)
+            self.engine.vertices_mutable[:] = self.verts
+        if has_r:
+            self.R = _bcast_array(R, ((3, 3), np.float32), self._src, dist, self._bdev)
+            if hasattr(self.engine, "set_raycast_axes"):
+                try:
+                    self.engine.set_raycast_axes(self.R, pin=2)  # takes effect at the update below
+                except TypeError:
+                    self.engine.set_raycast_axes(self.R)
+        self.engine.update()
 
     def local_range(self, n):
         return shard_range(n, self.rank, self.world)
@@ -101,7 +137,7 @@ class ShardedSDF:
         import torch.distributed as dist
         per = -(-n // self.world)
         buf = torch.zeros(per, dtype=dtype)
-        loc = torch.as_tensor(np.asarray(local)).to(dtype)
+        loc = (local.detach().cpu() if hasattr(local, "detach") else torch.as_tensor(np.asarray(local))).to(dtype)
         buf[: hi - lo] = loc
         outs = [torch.zeros(per, dtype=dtype) for _ in range(self.world)]
         if dist.get_backend() != "gloo":

@@ -56,6 +56,9 @@ ABI_SYMBOLS = [
     "sdfhip_set_option", "sdfhip_last_error", "sdfhip_version",
     "sdfhip_sample_surface", "sdfhip_sample_surface_device",
     "sdfhip_host_alloc", "sdfhip_host_free",
+    "sdfhip_group_create", "sdfhip_group_destroy", "sdfhip_group_size", "sdfhip_group_member",
+    "sdfhip_group_update", "sdfhip_group_set_raycast_axes", "sdfhip_group_get_raycast_axes",
+    "sdfhip_group_sdf", "sdfhip_group_contains", "sdfhip_group_nn",
     "sdfhip_renderer_create", "sdfhip_renderer_destroy", "sdfhip_renderer_update",
     "sdfhip_renderer_render_depth", "sdfhip_renderer_render_mask", "sdfhip_renderer_render_nn",
     "sdfhip_renderer_depth", "sdfhip_renderer_contains", "sdfhip_renderer_nn",
@@ -124,6 +127,19 @@ def load_library():
     L.sdfhip_sample_surface_device.argtypes = [vp, C.c_int64, C.c_uint64, vp, vp]
     L.sdfhip_get_stats.argtypes = [vp, C.POINTER(_Stats)]
     L.sdfhip_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.sdfhip_group_create.argtypes = [_fp, C.c_uint32, _up, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
+                                      C.POINTER(C.c_void_p)]
+    L.sdfhip_group_destroy.argtypes = [vp]
+    L.sdfhip_group_destroy.restype = None
+    L.sdfhip_group_size.argtypes = [vp]
+    L.sdfhip_group_member.argtypes = [vp, C.c_int]
+    L.sdfhip_group_member.restype = C.c_void_p
+    L.sdfhip_group_update.argtypes = [vp]
+    L.sdfhip_group_set_raycast_axes.argtypes = [vp, _fp, C.c_int]
+    L.sdfhip_group_get_raycast_axes.argtypes = [vp, _fp]
+    L.sdfhip_group_sdf.argtypes = [vp, _fp, C.c_int64, C.c_int, _fp]
+    L.sdfhip_group_contains.argtypes = [vp, _fp, C.c_int64, _bp]
+    L.sdfhip_group_nn.argtypes = [vp, _fp, C.c_int64, _ip]
     L.sdfhip_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.sdfhip_host_free.argtypes = [C.c_void_p]
     L.sdfhip_renderer_create.argtypes = [_fp, C.c_uint32, _up, C.c_uint32, C.c_int, C.c_int, C.c_float,
@@ -204,6 +220,81 @@ def _as_points(points):
     if p.ndim != 2 or p.shape[1] != 3:
         raise TypeError("points must have shape (N, 3)")
     return np.ascontiguousarray(p, dtype=np.float32)
+
+
+class GroupSDF:
+    """One mesh on several GPUs of this process (sdfhip_group_*): the host-array queries of `SDF`, the
+    points cut into contiguous ranges, one per listed device (an ordinal may repeat).  No counterpart in
+    pysdf; same query signatures and results as `SDF`."""
+
+    def __init__(self, verts, faces, robust=True, copy=True, devices=(0,)):
+        L = load_library()
+        v32 = np.ascontiguousarray(np.asarray(verts), dtype=np.float32)
+        f32 = np.ascontiguousarray(np.asarray(faces), dtype=np.uint32)
+        if v32.ndim != 2 or v32.shape[1] != 3 or f32.ndim != 2 or f32.shape[1] != 3:
+            raise TypeError("verts must be (V, 3) and faces (F, 3)")
+        if not copy and (not np.shares_memory(v32, verts) or not np.shares_memory(f32, faces)):
+            raise TypeError("copy=False needs C-contiguous float32 verts and uint32 faces")
+        self._keep = None if copy else (v32, f32)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        g = C.c_void_p()
+        _check(L.sdfhip_group_create(v32.ctypes.data_as(_fp), v32.shape[0], f32.ctypes.data_as(_up), f32.shape[0],
+                                     int(bool(robust)), int(bool(copy)), devs, len(devices), C.byref(g)))
+        self._g, self._L, self._nv, self._copy = g, L, v32.shape[0], bool(copy)
+
+    def __del__(self):
+        g = getattr(self, "_g", None)
+        if g:
+            self._L.sdfhip_group_destroy(g)
+            self._g = None
+
+    def __len__(self):
+        return self._L.sdfhip_group_size(self._g)
+
+    def __call__(self, points, trunc_aabb=False, n_threads=None):
+        p = _as_points(points)
+        out = np.empty(p.shape[0], dtype=np.float32)
+        _check(self._L.sdfhip_group_sdf(self._g, p.ctypes.data_as(_fp), p.shape[0], int(trunc_aabb),
+                                        out.ctypes.data_as(_fp)))
+        return out
+
+    calc = __call__
+
+    def contains(self, points, n_threads=None):
+        p = _as_points(points)
+        out = np.empty(p.shape[0], dtype=np.uint8)
+        _check(self._L.sdfhip_group_contains(self._g, p.ctypes.data_as(_fp), p.shape[0], out.ctypes.data_as(_bp)))
+        return out.astype(bool)
+
+    def nn(self, points, n_threads=None):
+        p = _as_points(points)
+        out = np.empty(p.shape[0], dtype=np.int32)
+        _check(self._L.sdfhip_group_nn(self._g, p.ctypes.data_as(_fp), p.shape[0], out.ctypes.data_as(_ip)))
+        return out
+
+    def update(self):
+        _check(self._L.sdfhip_group_update(self._g))
+
+    def set_raycast_axes(self, R, pin=True):
+        R = np.ascontiguousarray(R, dtype=np.float32).reshape(9)
+        _check(self._L.sdfhip_group_set_raycast_axes(self._g, R.ctypes.data_as(_fp), int(pin)))
+
+    @property
+    def raycast_axes(self):
+        R = np.empty(9, dtype=np.float32)
+        _check(self._L.sdfhip_group_get_raycast_axes(self._g, R.ctypes.data_as(_fp)))
+        return R.reshape(3, 3)
+
+    @property
+    def vertices_mutable(self):
+        """the owned host copy (member 0's; every member re-reads it on update())"""
+        if not self._copy:
+            raise SdfHipError("'verts' is non mutable, construct with copy=True")
+        h0 = self._L.sdfhip_group_member(self._g, 0)
+        ptr = self._L.sdfhip_verts_mutable(h0)
+        return np.ctypeslib.as_array(ptr, shape=(self._nv, 3))
+
+    verts_mutable = vertices_mutable
 
 
 class SDF:

@@ -37,8 +37,17 @@ def _worker(rank, world, port, outdir):
         v = f = R = None
 
     class Engine(po.OracleSDF):
-        def set_raycast_axes(self, R):
-            self.update(R)
+        def set_raycast_axes(self, R, pin=1):
+            self.R = np.ascontiguousarray(R, dtype=np.float32).reshape(3, 3)
+            if pin != 2:
+                po.OracleSDF.update(self, self.R)
+
+        @property
+        def vertices_mutable(self):
+            return self.verts  # the oracle reads this array again on update(), like Eigen::Ref
+
+        def update(self):
+            po.OracleSDF.update(self, self.R)
 
     s = ShardedSDF(v, f, robust=True, R=R, engine_factory=lambda vv, ff, rb: Engine(vv, ff, rb))
     n = 10007  # ragged: not divisible by world
@@ -51,6 +60,19 @@ def _worker(rank, world, port, outdir):
     full_nn = s.gather(n, lo, hi, nn, torch.int32)
     np.savez(os.path.join(outdir, f"r{rank}.npz"), lo=lo, hi=hi, d=d, c=c, nn=nn, full_d=full_d,
              full_nn=full_nn, verts=s.verts, R=s.R)
+    # deforming mesh (BASELINE config 5, demo.cpp:109-121): rank 0 moves the vertices, update() replicates
+    # them and a rotation (frame 1: drawn by rank 0 at random, frames 2-3: given), every rank rebuilds
+    v0 = s.verts.copy()
+    frames = {}
+    for t in (1, 2, 3):
+        vt = (v0 * (1 + 0.05 * np.sin(2 * np.pi * t / 100 + 4 * v0[:, 1:2]))).astype(np.float32) if rank == 0 else None
+        s.update(vt, None if t == 1 else (meshes.random_rotation(100 + t) if rank == 0 else None))
+        lo, hi, ct = s.contains_local(pts)
+        _, _, nt = s.nn_local(pts)
+        _, _, dt = s.sdf_local(pts)
+        frames[f"c{t}"], frames[f"n{t}"], frames[f"d{t}"] = ct, nt, dt
+        frames[f"v{t}"], frames[f"R{t}"] = s.verts.copy(), s.R.copy()
+    np.savez(os.path.join(outdir, f"f{rank}.npz"), **frames)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,3 +106,17 @@ def test_two_rank_gloo_sharded_queries_match_single_process(tmp_path):
         assert (g["c"] == ref_c[lo:hi]).all() and (g["nn"] == ref_nn[lo:hi]).all()
         assert (g["full_d"].view(np.uint32) == ref_d.view(np.uint32)).all()
         assert (g["full_nn"] == ref_nn).all()
+    # the three deformation frames: same vertices and R on both ranks, results = a single-process oracle
+    fr = [np.load(os.path.join(tmp_path, f"f{k}.npz")) for k in range(world)]
+    for t in (1, 2, 3):
+        vt = (v * (1 + 0.05 * np.sin(2 * np.pi * t / 100 + 4 * v[:, 1:2]))).astype(np.float32)
+        assert (fr[0][f"v{t}"] == vt).all() and (fr[1][f"v{t}"] == vt).all()
+        assert (fr[0][f"R{t}"] == fr[1][f"R{t}"]).all()
+        if t > 1:
+            assert (fr[0][f"R{t}"] == meshes.random_rotation(100 + t)).all()
+        ot = po.OracleSDF(vt, f, True, fr[0][f"R{t}"])
+        rc, rn, rd = ot.contains(pts), ot.nn(pts), ot(pts)
+        for k, g in enumerate(got):
+            lo, hi = int(g["lo"]), int(g["hi"])
+            assert (fr[k][f"c{t}"] == rc[lo:hi]).all() and (fr[k][f"n{t}"] == rn[lo:hi]).all()
+            assert (fr[k][f"d{t}"].view(np.uint32) == rd[lo:hi].view(np.uint32)).all()
