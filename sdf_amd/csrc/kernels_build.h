@@ -500,11 +500,75 @@ struct GridParams {
     float o0, o1, inv0, inv1;
 };
 constexpr uint32_t GRID_BIG = 256;  // faces touching more cells go to the "big" list
+constexpr uint32_t GRID_BIG_TRI = 16384;  // ... unless their triangle can be tested against the cells
+
+// A face is listed in the cells its rotated AABB touches: a rigorous superset of the faces that pass
+// Overlap for a query of the cell (kernels_query.h grid_cell).  For slivers (steep faces of a rough
+// surface: the AABB is 10-100 x the triangle) that superset is long, and so is the reference's own
+// candidate set; but a candidate only COUNTS when bary2d >= 0 as well (sdf.cpp:310), so a cell may drop
+// a face whose bary2d test is certainly false for every query point p of the cell that passes Overlap.
+// With a the first corner, v0 = b - a, v1 = c - a, v2 = p - a, den = v0 x v1 (sdf.hpp:130-142), u = 2^-24:
+//   b1 = (v2 x v1) / den.  The fp32 numerator differs from the exact one by <= 4.5u |v2| |v1| (two
+//   rounded products, one difference, rounded inputs), so its sign is the exact one whenever p is
+//   farther than 4.5u |v2| from the line (a, c); the same for b2 and the line (a, b).  The sign of the
+//   fp32 den is the exact one while kappa = |v0||v1| / |den| < 1 / (4.5u).
+//   b0 = 1 - (b1 + b2) = dist(p, line bc) / h_a.  |b0_fp32 - b0| <= 16u kappa |v2| (|v0| + |v1|) / |den| + 2u,
+//   i.e. b0_fp32 < 0 whenever p is farther outside (b, c) than 16u kappa |v2| (|v0| + |v1|) / |bc| + 2u h_a.
+// |v2| <= diagonal of the AABB for a p that passes Overlap.  The cell test below dilates the triangle by
+// 4 x the largest of these bounds plus the rounding slack of the cell function, and excludes a cell only
+// when one triangle edge separates the dilated triangle from the whole cell rectangle.  Faces that are
+// nearly degenerate (kappa > 1e4), tiny / huge, or non-finite keep the AABB rule.
+struct TriCell {
+    double nx[3], ny[3], off[3];  // outward unit normals of the edges, n . (point on the edge)
+    double m;                     // dilation
+    bool on;
+};
+__device__ __forceinline__ TriCell tri_cell_setup(const float* bx, const float4 f0, const float4 f1, double slack) {
+    TriCell T;
+    T.on = false;
+    T.m = 0;
+    const double ax = f0.x, ay = f0.y, bxx = f0.w, by = f1.x, cx = f1.z, cy = f1.w;
+    const double v0x = bxx - ax, v0y = by - ay, v1x = cx - ax, v1y = cy - ay;
+    const double den = v0x * v1y - v1x * v0y;
+    const double l0 = sqrt(v0x * v0x + v0y * v0y), l1 = sqrt(v1x * v1x + v1y * v1y);
+    const double ex = cx - bxx, ey = cy - by, lbc = sqrt(ex * ex + ey * ey);
+    const double D = sqrt(((double)bx[3] - bx[0]) * ((double)bx[3] - bx[0]) + ((double)bx[4] - bx[1]) * ((double)bx[4] - bx[1]));
+    const double aden = fabs(den);
+    if (!(aden > 1e-30 && aden < 1e30 && l0 > 0 && l1 > 0 && lbc > 0 && D < 1e15)) return T;
+    const double kappa = l0 * l1 / aden;
+    if (!(kappa < 1e4)) return T;
+    const double u = 5.9604644775390625e-8;
+    const double m0 = 16.0 * u * kappa * D * (l0 + l1) / lbc + 2.0 * u * aden / lbc;
+    const double m1 = 4.5 * u * D;
+    T.m = 4.0 * (m0 > m1 ? m0 : m1) + slack;
+    if (!(T.m < 1e30)) return T;
+    const double sgn = den > 0 ? 1.0 : -1.0;  // counter-clockwise: outward normal of p0 -> p1 is (dy, -dx)
+    const double px[3] = {ax, bxx, cx}, py[3] = {ay, by, cy};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int e1 = e == 2 ? 0 : e + 1;
+        const double dx = px[e1] - px[e], dy = py[e1] - py[e], len = sqrt(dx * dx + dy * dy);
+        T.nx[e] = sgn * dy / len, T.ny[e] = -sgn * dx / len;
+        T.off[e] = T.nx[e] * px[e] + T.ny[e] * py[e];
+    }
+    T.on = true;
+    return T;
+}
+// true: no query point of the rectangle [x0, x1] x [y0, y1] can have bary2d >= 0 for this face
+__device__ __forceinline__ bool tri_cell_excluded(const TriCell& T, double x0, double x1, double y0, double y1) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const double mn = T.nx[e] * (T.nx[e] > 0 ? x0 : x1) + T.ny[e] * (T.ny[e] > 0 ? y0 : y1);
+        if (mn - T.off[e] > T.m) return true;
+    }
+    return false;
+}
 template <bool FILL>
 __global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridParams G,
                              uint32_t* __restrict__ cells /* counts | cursors */,
                              uint32_t* __restrict__ items, uint32_t* __restrict__ big,
-                             uint32_t* __restrict__ nbig, int skip_nan) {
+                             uint32_t* __restrict__ nbig, int skip_nan,
+                             const float4* __restrict__ rface /* a' b' c' n' per face, or nullptr: boxes only */) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nf) return;
     const float* b = fbox + 6 * (size_t)f;
@@ -514,12 +578,25 @@ __global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridPa
     const int y0 = grid_cell(b[1], G.o1, G.inv1, G.g), y1 = grid_cell(b[4], G.o1, G.inv1, G.g);
     if (x1 < x0 || y1 < y0) return;  // NaN box: the face can never pass Overlap
     const uint32_t nc = (uint32_t)(x1 - x0 + 1) * (uint32_t)(y1 - y0 + 1);
-    if (nc > GRID_BIG) {
+    TriCell T;
+    T.on = false;
+    const double wx = G.inv0 > 0.f ? 1.0 / (double)G.inv0 : 0.0, wy = G.inv1 > 0.f ? 1.0 / (double)G.inv1 : 0.0;
+    if (rface && nc > 1u && wx > 0.0 && wy > 0.0) {
+        // slack of the cell function (subtract, multiply, floor in fp32): a few ulps of the grid's span
+        const double span = fabs((double)G.o0) + fabs((double)G.o1) + (double)G.g * (wx + wy);
+        T = tri_cell_setup(b, rface[3 * (size_t)f], rface[3 * (size_t)f + 1], 1e-6 * span);
+    }
+    if (nc > (T.on ? GRID_BIG_TRI : GRID_BIG)) {
         if (!FILL) big[atomicAdd(nbig, 1u)] = f;
         return;
     }
     for (int y = y0; y <= y1; ++y)
         for (int x = x0; x <= x1; ++x) {
+            if (T.on) {  // border cells take everything beyond the grid's range
+                const double rx0 = x == 0 ? -1e30 : (double)G.o0 + x * wx, rx1 = x == G.g - 1 ? 1e30 : (double)G.o0 + (x + 1) * wx;
+                const double ry0 = y == 0 ? -1e30 : (double)G.o1 + y * wy, ry1 = y == G.g - 1 ? 1e30 : (double)G.o1 + (y + 1) * wy;
+                if (tri_cell_excluded(T, rx0, rx1, ry0, ry1)) continue;
+            }
             const uint32_t c = (uint32_t)y * (uint32_t)G.g + (uint32_t)x;
             if (FILL)
                 items[atomicAdd(&cells[c], 1u)] = f;

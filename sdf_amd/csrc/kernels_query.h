@@ -259,10 +259,18 @@ __device__ __forceinline__ int grid_cell(float v, float o, float inv, int g) {
     if (f >= (float)(g - 1)) return g - 1;
     return (int)f;
 }
+#ifdef SDFK_STATS
+__device__ unsigned long long g_ray_stats[4];  // queries in the box, faces tested, faces passing Overlap in xy, bary2d evaluated
+#define SDFK_RCOUNT(K) atomicAdd(&g_ray_stats[K], 1ull)
+#else
+#define SDFK_RCOUNT(K)
+#endif
 __device__ __forceinline__ void ray_face_z(const MeshDev& M, V3 q, uint32_t face, int& zp, int& zm) {
     const float* bx = M.fbox + 6 * (size_t)face;
     const float mnx = bx[0], mny = bx[1], mnz = bx[2], mxx = bx[3], mxy = bx[4], mxz = bx[5];
+    SDFK_RCOUNT(1);
     if ((q.x > mxx || mnx > q.x) || (q.y > mxy || mny > q.y)) return;  // Overlap, x and y
+    SDFK_RCOUNT(2);
     const bool okp = !(q.z > mxz || mnz > FLT_MAX);   // box [q.z, FLT_MAX]
     const bool okm = !(-FLT_MAX > mxz || mnz > q.z);  // box [-FLT_MAX, q.z]
     const float4 f0 = M.rface[3 * (size_t)face];      // a'.xyz b'.x
@@ -273,6 +281,7 @@ __device__ __forceinline__ void ray_face_z(const MeshDev& M, V3 q, uint32_t face
     const float s = sdfk::dot(nr, dv) * nr.z;  // sdf.cpp:301-302, ax_idx = 2
     const bool pos = s > 0.f;                  // z- needs pos, z+ needs !pos
     if (pos ? okm : okp) {
+        SDFK_RCOUNT(3);
         if (sdfk::bary2d_inside(q.x, q.y, f0.x, f0.y, f0.w, f1.x, f1.z, f1.w)) {
             if (pos)
                 zm ^= 1;
@@ -284,6 +293,7 @@ __device__ __forceinline__ void ray_face_z(const MeshDev& M, V3 q, uint32_t face
 __device__ __forceinline__ void ray_z_pair_grid(const MeshDev& M, V3 q, int& zp, int& zm) {
     zp = 0;
     zm = 0;
+    SDFK_RCOUNT(0);
     const int cx = grid_cell(q.x, M.gr_o0, M.gr_inv0, M.gr_g), cy = grid_cell(q.y, M.gr_o1, M.gr_inv1, M.gr_g);
     const uint32_t c = (uint32_t)cy * (uint32_t)M.gr_g + (uint32_t)cx;
     const uint32_t e = M.gr_start[c + 1];

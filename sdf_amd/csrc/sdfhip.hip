@@ -202,6 +202,8 @@ struct sdfhip_ctx {
     uint32_t* d_vkeys = nullptr;
     uint32_t* d_vidx = nullptr;
     size_t vkeys_cap = 0;
+    int64_t opt_grid_per_face = 16;  // column grid: halve the resolution while the lists exceed this many entries per face
+    int64_t opt_grid_tri = 1;  // column grid: cells drop faces whose triangle cannot contain their points
     int64_t opt_ray_mode = 0;  // 0 automatic, 1 column grid, 2 cooperative LBVH (packet kernel)
     float* d_normals = nullptr;
     float* d_areas = nullptr;
@@ -357,7 +359,7 @@ void draw_rotation(sdfhip_ctx* h) {
 // x / y range is [lo, hi]: count -> scan -> fill, three small launches (+ one retry per halving
 // when the faces are large against the cells).
 int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], const float hi[2],
-               int skip_nan, hipStream_t s) {
+               int skip_nan, hipStream_t s, const float4* d_rface = nullptr, int64_t max_per_face = 16) {
     if (n == 0) {  // no faces: one empty cell (the query kernels always look their cell up)
         if (B.cells_cap < 2) {
             if (int rc = dalloc(&B.start, 2)) return rc;
@@ -396,7 +398,7 @@ int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], c
         HIPC(hipMemsetAsync(B.start, 0, sizeof(uint32_t) * cells, s));
         HIPC(hipMemsetAsync(B.nbig_dev, 0, sizeof(uint32_t), s));
         k_grid_faces<false><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.start, nullptr, B.big,
-                                                            B.nbig_dev, skip_nan);
+                                                            B.nbig_dev, skip_nan, d_rface);
         exclusive_scan_u32(B.start, (uint32_t)cells, B.s1, B.s2, s);
         uint32_t total = 0, nbig = 0;
         HIPC(hipMemcpyAsync(&total, B.start + (cells - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -404,7 +406,7 @@ int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], c
         HIPC(hipStreamSynchronize(s));
         if (g == g_first) long_lists = (size_t)total + 256 * (size_t)nbig > 10 * (size_t)n;
         // many faces much larger than a cell: a coarser grid keeps the lists (and memory) short
-        if (((size_t)total > 16 * (size_t)n + 4096 || (size_t)nbig > (size_t)n / 64 + 16) && g > 1) {
+        if (((size_t)total > (size_t)max_per_face * (size_t)n + 4096 || (size_t)nbig > (size_t)n / 64 + 16) && g > 1) {
             g = g / 2;
             continue;
         }
@@ -415,7 +417,7 @@ int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], c
         }
         HIPC(hipMemcpyAsync(B.cursor, B.start, sizeof(uint32_t) * cells, hipMemcpyDeviceToDevice, s));
         k_grid_faces<true><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.cursor, B.items, B.big,
-                                                           B.nbig_dev, skip_nan);
+                                                           B.nbig_dev, skip_nan, d_rface);
         HIPC(hipGetLastError());
         B.gr = G;
         B.coarsened = long_lists;
@@ -494,7 +496,7 @@ int build_grid(sdfhip_ctx* h) {
             hi[d] = r > hi[d] ? r : hi[d];
         }
     }
-    return grid_build(h->grid, h->d_fbox, h->nf, lo, hi, 0, h->stream);
+    return grid_build(h->grid, h->d_fbox, h->nf, lo, hi, 0, h->stream, h->opt_grid_tri ? h->d_rface : nullptr, h->opt_grid_per_face);
 }
 
 // rotation-dependent + vertex-dependent precompute; verts must already be in d_verts
@@ -1643,6 +1645,15 @@ int sdfhip_sample_surface(sdfhip_t* h, int64_t n, uint64_t seed, float* out) {
     return rc;
 }
 #ifdef SDFK_STATS
+int sdfhip_debug_ray_stats(unsigned long long out[4], int reset) {
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_stats), 4 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        HIPC(hipMemcpyToSymbol(HIP_SYMBOL(g_ray_stats), z, sizeof(z)));
+    }
+    return 0;
+}
 int sdfhip_debug_packet_stats(unsigned long long out[8], int reset) {
     HIPC(hipDeviceSynchronize());
     HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_stats), 8 * sizeof(unsigned long long)));
@@ -1694,6 +1705,11 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
     else if (!strcmp(key, "ray_mode")) {
         if (v < 0 || v > 2) return fail(SDFHIP_E_INVALID, "ray_mode must be 0 (auto), 1 (grid) or 2 (LBVH)");
         h->opt_ray_mode = v;
+    } else if (!strcmp(key, "grid_per_face")) {
+        if (v < 1 || v > 4096) return fail(SDFHIP_E_INVALID, "grid_per_face must be in [1, 4096]");
+        h->opt_grid_per_face = v;  // takes effect at the next update / set_raycast_axes
+    } else if (!strcmp(key, "grid_tri")) {
+        h->opt_grid_tri = v ? 1 : 0;  // takes effect at the next update / set_raycast_axes
     } else if (!strcmp(key, "host_chunk")) {
         if (v != 0 && (v < 1024 || v > (1ll << 27)))
             return fail(SDFHIP_E_INVALID, "host_chunk must be 0 (automatic) or in [1024, 2^27]");

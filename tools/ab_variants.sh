@@ -1,5 +1,4 @@
-for L in sdf_amd/libsdfhip*.so; do
-  case $L in *stats*) continue;; esac
-  echo "== $L"
-  SDFHIP_LIB=$PWD/$L timeout -k 10 120 python tools/perf_probe.py --n 64000000 ${AB_ARGS:---only nn} 2>&1 | grep -E "^(nn|sdf|contains)"
+for o in "grid_per_face=16" "grid_per_face=40" "grid_per_face=100" "grid_tri=0"; do
+  echo "== $o"
+  SDFHIP_DEBUG=1 timeout -k 10 100 python tools/perf_probe.py --mesh ico7 --n 64000000 --only contains --ray-mode 1 --opt $o 2>&1 | grep -E "^contains|column grid" | tail -2
 done

@@ -20,6 +20,7 @@ ap.add_argument("--noise", type=float, default=0.05)
 ap.add_argument("--group", type=int, default=0, help="packet_group option (0 = library default)")
 ap.add_argument("--heavy-budget", type=int, default=0)
 ap.add_argument("--chunk", type=int, default=0)
+ap.add_argument("--opt", action="append", default=[], help="key=value handle option, set before the rotation is pinned")
 ap.add_argument("--rmin", type=float, default=0.0, help="drop points closer than this to the origin")
 a = ap.parse_args()
 if a.mesh.startswith("ico"):
@@ -35,6 +36,9 @@ s = sdf_amd.SDF(v, f, robust=bool(a.robust))
 if a.group:
     s.set_option("packet_group", a.group)
     s.update()
+for kv in a.opt:
+    k, v_ = kv.split("=")
+    s.set_option(k, int(v_))
 s.set_raycast_axes(meshes.random_rotation(1234))
 dev = torch.device("cuda", 0)
 if a.grid:
