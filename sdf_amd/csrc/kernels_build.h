@@ -568,7 +568,8 @@ __global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridPa
                              uint32_t* __restrict__ cells /* counts | cursors */,
                              uint32_t* __restrict__ items, uint32_t* __restrict__ big,
                              uint32_t* __restrict__ nbig, int skip_nan,
-                             const float4* __restrict__ rface /* a' b' c' n' per face, or nullptr: boxes only */) {
+                             const float4* __restrict__ rface /* a' b' c' n' per face, or nullptr: boxes only */,
+                             float4* __restrict__ ibox /* FILL: the face's x, y box beside its id, or nullptr */) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nf) return;
     const float* b = fbox + 6 * (size_t)f;
@@ -598,10 +599,13 @@ __global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridPa
                 if (tri_cell_excluded(T, rx0, rx1, ry0, ry1)) continue;
             }
             const uint32_t c = (uint32_t)y * (uint32_t)G.g + (uint32_t)x;
-            if (FILL)
-                items[atomicAdd(&cells[c], 1u)] = f;
-            else
+            if (FILL) {
+                const uint32_t slot = atomicAdd(&cells[c], 1u);
+                items[slot] = f;
+                if (ibox) ibox[slot] = make_float4(b[0], b[1], b[3], b[4]);
+            } else {
                 atomicAdd(&cells[c], 1u);
+            }
         }
 }
 

@@ -45,6 +45,7 @@ struct MeshDev {
     const float* fbox;          // per face: rotated AABB min xyz, max xyz
     const uint32_t* gr_start;   // [g*g + 1]
     const uint32_t* gr_items;   // face ids, cell by cell
+    const float4* gr_ibox;      // per entry of gr_items: the face's rotated AABB in x', y' {mnx, mny, mxx, mxy}
     const uint32_t* gr_big;     // faces spanning too many cells: tested by every query
     uint32_t gr_nbig;
     int ray_lbvh;  // packet kernel: walk the LBVH cooperatively instead of the grid (long lists)
@@ -290,6 +291,30 @@ __device__ __forceinline__ void ray_face_z(const MeshDev& M, V3 q, uint32_t face
         }
     }
 }
+// The part of ray_face_z after Overlap in x and y: the z side of Overlap, facing rule, bary2d.  The z range
+// of the face's box is recomputed from its rotated corners exactly as k_face_precompute stored it.
+__device__ __forceinline__ void ray_face_z_rest(V3 q, const float4 f0, const float4 f1, const float4 f2, int& zp,
+                                                int& zm) {
+    const float mnz = sdfk::stdmin(sdfk::stdmin(f0.z, f1.y), f2.x), mxz = sdfk::stdmax(sdfk::stdmax(f0.z, f1.y), f2.x);
+    const bool okp = !(q.z > mxz || mnz > FLT_MAX);   // box [q.z, FLT_MAX]
+    const bool okm = !(-FLT_MAX > mxz || mnz > q.z);  // box [-FLT_MAX, q.z]
+    const V3 nr = {f2.y, f2.z, f2.w};
+    const V3 dv = sdfk::sub(q, V3{f0.x, f0.y, f0.z});
+    const float s = sdfk::dot(nr, dv) * nr.z;  // sdf.cpp:301-302, ax_idx = 2
+    const bool pos = s > 0.f;                  // z- needs pos, z+ needs !pos
+    if (pos ? okm : okp) {
+        SDFK_RCOUNT(3);
+        if (sdfk::bary2d_inside(q.x, q.y, f0.x, f0.y, f0.w, f1.x, f1.z, f1.w)) {
+            if (pos)
+                zm ^= 1;
+            else
+                zp ^= 1;
+        }
+    }
+}
+// The cell's list carries each face's x', y' box next to its id (cell-major, read as a stream): only faces
+// that pass Overlap in x and y (a third to two thirds of the list) fetch their 48-byte record.  Two entries
+// per step, their loads in flight together.
 __device__ __forceinline__ void ray_z_pair_grid(const MeshDev& M, V3 q, int& zp, int& zm) {
     zp = 0;
     zm = 0;
@@ -297,7 +322,26 @@ __device__ __forceinline__ void ray_z_pair_grid(const MeshDev& M, V3 q, int& zp,
     const int cx = grid_cell(q.x, M.gr_o0, M.gr_inv0, M.gr_g), cy = grid_cell(q.y, M.gr_o1, M.gr_inv1, M.gr_g);
     const uint32_t c = (uint32_t)cy * (uint32_t)M.gr_g + (uint32_t)cx;
     const uint32_t e = M.gr_start[c + 1];
-    for (uint32_t k = M.gr_start[c]; k < e; ++k) ray_face_z(M, q, M.gr_items[k], zp, zm);
+    for (uint32_t k = M.gr_start[c]; k < e; k += 2u) {
+        const uint32_t k1 = k + 1u < e ? k + 1u : k;
+        const float4 b0 = M.gr_ibox[k], b1 = M.gr_ibox[k1];
+        const uint32_t i0 = M.gr_items[k], i1 = M.gr_items[k1];
+        const bool in0 = !((q.x > b0.z || b0.x > q.x) || (q.y > b0.w || b0.y > q.y));
+        const bool in1 = k1 != k && !((q.x > b1.z || b1.x > q.x) || (q.y > b1.w || b1.y > q.y));
+        SDFK_RCOUNT(1);
+        if (k1 != k) SDFK_RCOUNT(1);
+        float4 f00, f01, f02, f10, f11, f12;
+        if (in0) f00 = M.rface[3 * (size_t)i0], f01 = M.rface[3 * (size_t)i0 + 1], f02 = M.rface[3 * (size_t)i0 + 2];
+        if (in1) f10 = M.rface[3 * (size_t)i1], f11 = M.rface[3 * (size_t)i1 + 1], f12 = M.rface[3 * (size_t)i1 + 2];
+        if (in0) {
+            SDFK_RCOUNT(2);
+            ray_face_z_rest(q, f00, f01, f02, zp, zm);
+        }
+        if (in1) {
+            SDFK_RCOUNT(2);
+            ray_face_z_rest(q, f10, f11, f12, zp, zm);
+        }
+    }
     for (uint32_t k = 0; k < M.gr_nbig; ++k) ray_face_z(M, q, M.gr_big[k], zp, zm);
 }
 

@@ -108,6 +108,8 @@ struct GridBuf {
     uint32_t* start = nullptr;   // [g*g + 1]
     uint32_t* cursor = nullptr;
     uint32_t* items = nullptr;
+    float4* ibox = nullptr;      // per entry of items: the face's box in x, y (only when want_ibox)
+    bool want_ibox = false;
     uint32_t* big = nullptr;
     uint32_t* nbig_dev = nullptr;
     uint32_t* s1 = nullptr;
@@ -117,10 +119,11 @@ struct GridBuf {
     bool coarsened = false;  // faces are large against the cells at the natural resolution
     GridParams gr = {1, 0.f, 0.f, 0.f, 0.f};
     void release() {
-        void* ps[] = {start, cursor, items, big, nbig_dev, s1, s2};
+        void* ps[] = {start, cursor, items, ibox, big, nbig_dev, s1, s2};
         for (void* p : ps)
             if (p) (void)hipFree(p);
         start = cursor = items = big = nbig_dev = s1 = s2 = nullptr;
+        ibox = nullptr;
         cells_cap = items_cap = big_cap = 0;
     }
 };
@@ -398,7 +401,7 @@ int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], c
         HIPC(hipMemsetAsync(B.start, 0, sizeof(uint32_t) * cells, s));
         HIPC(hipMemsetAsync(B.nbig_dev, 0, sizeof(uint32_t), s));
         k_grid_faces<false><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.start, nullptr, B.big,
-                                                            B.nbig_dev, skip_nan, d_rface);
+                                                            B.nbig_dev, skip_nan, d_rface, nullptr);
         exclusive_scan_u32(B.start, (uint32_t)cells, B.s1, B.s2, s);
         uint32_t total = 0, nbig = 0;
         HIPC(hipMemcpyAsync(&total, B.start + (cells - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -413,11 +416,13 @@ int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], c
         if ((size_t)total + 1 > B.items_cap) {
             const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
             if (int rc = dalloc(&B.items, cap)) return rc;
+            if (B.want_ibox)
+                if (int rc = dalloc(&B.ibox, cap)) return rc;
             B.items_cap = cap;
         }
         HIPC(hipMemcpyAsync(B.cursor, B.start, sizeof(uint32_t) * cells, hipMemcpyDeviceToDevice, s));
         k_grid_faces<true><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.cursor, B.items, B.big,
-                                                           B.nbig_dev, skip_nan, d_rface);
+                                                           B.nbig_dev, skip_nan, d_rface, B.want_ibox ? B.ibox : nullptr);
         HIPC(hipGetLastError());
         B.gr = G;
         B.coarsened = long_lists;
@@ -496,6 +501,7 @@ int build_grid(sdfhip_ctx* h) {
             hi[d] = r > hi[d] ? r : hi[d];
         }
     }
+    h->grid.want_ibox = true;
     return grid_build(h->grid, h->d_fbox, h->nf, lo, hi, 0, h->stream, h->opt_grid_tri ? h->d_rface : nullptr, h->opt_grid_per_face);
 }
 
@@ -777,13 +783,18 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.fbox = h->d_fbox;
     M.gr_start = h->grid.start;
     M.gr_items = h->grid.items;
+    M.gr_ibox = h->grid.ibox;
     M.gr_big = h->grid.big;
     M.gr_nbig = h->robust ? h->grid.nbig : 0;
     M.gr_g = h->grid.gr.g;
-    // automatic: faces that touch > 10 cells each at the natural resolution are large against
-    // the cells and the per-lane lists are long; the wave-cooperative LBVH walk shares them
-    // among 64 lanes
-    M.ray_lbvh = h->opt_ray_mode == 2 || (h->opt_ray_mode == 0 && h->grid.coarsened) ? 1 : 0;
+    // automatic: the wave-cooperative LBVH walk shares long candidate lists among 64 lanes.  It pays when
+    // many faces span too many cells to be listed (every query tests the "big" list), or — without the
+    // triangle filter of the cells — when faces touch > 10 cells each at the natural resolution.  With the
+    // filter the grid wins also on rough surfaces (noisy icosphere-7, 64M points: 28 against 55 ms).
+    M.ray_lbvh = h->opt_ray_mode == 2 ||
+                         (h->opt_ray_mode == 0 && (h->grid.nbig > 64u || (h->grid.coarsened && !h->opt_grid_tri)))
+                     ? 1
+                     : 0;
     M.gr_o0 = h->grid.gr.o0, M.gr_o1 = h->grid.gr.o1, M.gr_inv0 = h->grid.gr.inv0, M.gr_inv1 = h->grid.gr.inv1;
     for (int d = 0; d < 9; ++d) M.R[d] = h->R[d];
     return M;
