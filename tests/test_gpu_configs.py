@@ -87,6 +87,41 @@ def test_config5_deforming_mesh_frames():
     assert ((ana > 0) == s2.contains(pts))[far].all()
 
 
+def test_config5_full_size_pipelined_frames():
+    """BASELINE config 5 at its own size: torus 424 x 424 (359,552 faces), 4M device-resident points, frames of
+    vertices_mutable + update() + contains() + nn() issued back to back (the queries are asynchronous on the
+    stream; the host kd-tree build of frame t+1 overlaps the GPU work of frame t), results kept on the device
+    and a sample of every frame checked against the oracle afterwards."""
+    import time
+    import torch
+    v0, f = meshes.torus(424, 424)
+    R = meshes.random_rotation(4)
+    s = SDF(v0, f, robust=True, copy=True)
+    s.set_raycast_axes(R)
+    dev = torch.device("cuda", 0)
+    pts = torch.rand((4_000_000, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(7)).mul_(2).sub_(1)
+    frames = 8
+    vs = [(v0 * (1 + 0.05 * np.sin(2 * np.pi * t / 100 + 4 * v0[:, 1:2]))).astype(np.float32) for t in range(frames)]
+    res = []
+    for t in range(frames):
+        if t == 2:  # the first two frames warm the workspaces up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        s.vertices_mutable = vs[t]
+        s.update()
+        res.append((s.contains(pts), s.nn(pts)))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / (frames - 2) * 1e3
+    print(f"config 5, full size: {ms:.2f} ms per frame (update + contains(4M) + nn(4M))")
+    assert ms < 12.0  # measured 4.2 ms on MI355X; the bound only catches a lost overlap or a slow path
+    sub = torch.randint(0, pts.shape[0], (3000,), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    h = pts[sub].cpu().numpy()
+    for t in range(frames):
+        o = po.OracleSDF(vs[t], f, True, R)
+        assert (res[t][0][sub].cpu().numpy().astype(bool) == o.contains(h)).all()
+        assert (res[t][1][sub].cpu().numpy() == o.nn(h)).all()
+
+
 def test_update_from_device_tensor():
     import torch
     v0, f = meshes.torus(60, 60)

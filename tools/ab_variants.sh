@@ -1,4 +1,4 @@
-for o in "grid_per_face=16" "grid_per_face=40"; do
-  echo "== $o"
-  SDFHIP_DEBUG=1 timeout -k 10 100 python tools/perf_probe.py --mesh ico7 --n 64000000 --only contains --ray-mode 1 --opt $o 2>&1 | grep -E "^contains|column grid" | tail -2
+for hb in 500 1000 2000 4000 6000; do
+  echo "== heavy budget $hb"
+  timeout -k 10 100 python tools/perf_probe.py --n 4000000 --only nn --heavy-budget $hb --reps 5 2>&1 | tail -1
 done
