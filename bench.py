@@ -158,14 +158,18 @@ def main():
 
     total = n * world * a.steps
     value = total / dt
-    # dominant kernel: k_query_packet<SDF, robust>; algorithmic bytes per launch = 16 B x points/launch
+    # dominant kernel: the one the library reports for the last call (sdfhip_stats_t::last_kernel);
+    # algorithmic bytes per launch = 16 B x points/launch
     kl = max(1, st["query_kernel_launches"])
     k_ms = st["query_kernel_ms"] / kl
     pts_per_launch = st["query_kernel_points"] / kl
     achieved = BYTES_PER_EVAL * pts_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "k_query_packet<Q_SDF,robust,approx>", "kernel_ms_avg": k_ms,
+                "kernel": {2: "k_query_packet<Q_SDF,robust,exact walk>", 3: "k_query_packet<Q_SDF,robust,approx walk>",
+                           1: "k_query<Q_SDF,robust> (strict)", 4: "k_query_heavy<Q_SDF,robust> (scan)"}.get(
+                               st.get("last_kernel", 0), "unknown"),
+                "kernel_ms_avg": k_ms,
                 "points_per_launch": pts_per_launch, "launches": kl,
                 "kernel_share_of_step": st["query_kernel_ms"] / (dt * 1e3)}
     # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes of this same
@@ -175,8 +179,12 @@ def main():
         pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
         pm = json.load(open(pj))
         if pm.get("traffic_bytes_per_launch") and n == 125_000_000 and not a.no_sort:
+            # NOT measured by this run: PMC counters need their own rocprofv3 passes
             roofline["traffic"] = pm["traffic_bytes_per_launch"]
-            roofline["traffic_source"] = os.path.relpath(pj, ROOT)
+            roofline["traffic_source"] = "stored profile " + os.path.relpath(pj, ROOT)
+            for k in ("traffic_low", "traffic_high"):
+                if pm.get(k) is not None:
+                    roofline[k] = pm[k]
             # VALU utilisation of the same launch from the SQ counters of the same profile
             # (issue slots of 1024 SIMDs at 2 cycles per wave64 instruction; active lanes)
             for k in ("valu_issue_util", "valu_lane_util"):
@@ -210,8 +218,8 @@ def main():
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[3]: torus {res}x{res} ({nv} verts / {nf} faces), robust "
-                               f"SDF on {n} uniform random points in [-1,1]^3 per GPU per step "
-                               f"(1e9/8 per GPU), device-resident, seed 7+rank",
+                               f"SDF on {n} uniform random points in [-1,1]^3 per GPU per step"
+                               + (" (1e9/8 per GPU)" if n == 125_000_000 else "") + ", device-resident, seed 7+rank",
                    "points_per_gpu": n, "faces": nf, "verts": nv, "sort_queries": not a.no_sort},
         "roofline": roofline,
     }

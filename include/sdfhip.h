@@ -192,7 +192,17 @@ typedef struct {
     /* queries of the last call whose wave exceeded its work budget in the packet pass and were
      * answered by the one-wave-per-query kernel (option "heavy_budget") */
     int64_t last_heavy_points;
+    /* the kernel that answered (most of) the last query call: SDFHIP_KERNEL_* */
+    int32_t last_kernel;
+    int32_t reserved;
 } sdfhip_stats_t;
+enum {
+    SDFHIP_KERNEL_NONE = 0,
+    SDFHIP_KERNEL_STRICT = 1,        /* k_query: one lane per query, exact nanoflann emulation */
+    SDFHIP_KERNEL_PACKET_EXACT = 2,  /* k_query_packet<kind, robust, false>: wide walk, exact evaluation */
+    SDFHIP_KERNEL_PACKET_APPROX = 3, /* k_query_packet<kind, robust, true>: approximate first pass + exact second phase */
+    SDFHIP_KERNEL_SCAN = 4           /* k_query_heavy in scan mode: small batches */
+};
 int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* out);
 
 /* ---------------------------------------------------------------------------------------------

@@ -242,6 +242,7 @@ struct sdfhip_ctx {
     bool query_pending = false;
     std::mt19937 rng;
     float last_update_ms = 0.f, last_kd_ms = 0.f;
+    int last_kernel = SDFHIP_KERNEL_NONE;  // dominant kernel of the last query call (sdfhip_stats_t::last_kernel)
     // optional live profiling of the query kernels (hipEvents on the launch stream)
     int64_t opt_profile = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending, prof_free;
@@ -922,6 +923,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         const int64_t packs = (n + HEAVY_Q - 1) / HEAVY_Q;
         // kinds with a tail: positions first, then one lane per query for ray parity + face distances
         int32_t* pos = KIND == Q_NN ? nullptr : (int32_t*)(W.fb_list + W.fb_cap);
+        h->last_kernel = SDFHIP_KERNEL_SCAN;
         ProfScope prof{h, s};
         if (int rc = prof.begin()) return rc;
         if (packs <= 1024)  // few queries: 16 waves share each scan (the chain of one wave is ~0.4 ms at 190k)
@@ -1020,7 +1022,9 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             if (int rc = prof.begin()) return rc;
             // strict mode: approximate first pass + exact second phase (kernels_packet.h); the GPU-built
             // tree of fast_nn has no strict kernel behind it and keeps the exact walk
-            if (!fast && (h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0))
+            const bool approx = !fast && (h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0);
+            h->last_kernel = approx ? SDFHIP_KERNEL_PACKET_APPROX : SDFHIP_KERNEL_PACKET_EXACT;
+            if (approx)
                 k_query_packet<PK, ROBUST, true><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, 0, s>>>(
                     M, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
                     W.fb_list + W.fb_cap, W.fb_count + 2);
@@ -1042,6 +1046,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             flip ^= 1;
             deferred_pts += m;
         } else {
+            h->last_kernel = SDFHIP_KERNEL_STRICT;
             ProfScope prof{h, s};
             if (int rc = prof.begin()) return rc;
             if (int rc = launch_strict<KIND, ROBUST>(h, M, p, perm, m, trunc, o, nullptr, s)) return rc;
@@ -1616,6 +1621,7 @@ int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* o) {
     o->query_kernel_points = h->prof_points;
     o->last_fallback_points = 0;
     o->last_heavy_points = 0;
+    o->last_kernel = h->last_kernel;
     if (h->h_counts) {
         // the counters arrive by an asynchronous copy on the query's stream: wait for that query
         DevGuard g(h->device);

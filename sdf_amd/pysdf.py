@@ -39,7 +39,12 @@ class _Stats(C.Structure):
                 ("bvh_depth", C.c_int32), ("last_update_ms", C.c_float),
                 ("last_kd_build_ms", C.c_float), ("query_kernel_ms", C.c_double),
                 ("query_kernel_launches", C.c_int64), ("query_kernel_points", C.c_int64),
-                ("last_fallback_points", C.c_int64), ("last_heavy_points", C.c_int64)]
+                ("last_fallback_points", C.c_int64), ("last_heavy_points", C.c_int64),
+                ("last_kernel", C.c_int32), ("reserved", C.c_int32)]
+
+
+KERNEL_NAMES = {0: "none", 1: "k_query (strict)", 2: "k_query_packet<exact walk>", 3: "k_query_packet<approx walk>",
+                4: "k_query_heavy (scan)"}
 
 
 _lib = None
@@ -337,6 +342,17 @@ class SDF:
     # ---- queries -----------------------------------------------------------------------
     def _query(self, kind, points, trunc_aabb=False, out=None):
         L = self._L
+        if not _is_torch(points) and not isinstance(points, np.ndarray) and hasattr(points, "__dlpack__") \
+                and hasattr(points, "__dlpack_device__"):
+            # DLPack producers other than torch (CuPy, JAX, another framework's tensors): device arrays
+            # (kDLCUDA = 2, kDLROCM = 10) reach the `_device` entry points without a copy, and the result
+            # is a torch tensor on that device (itself a DLPack producer: `xp.from_dlpack(result)`);
+            # host arrays take the numpy path.  pybind.cpp:23-31 accepts host arrays only.
+            import torch
+            if int(points.__dlpack_device__()[0]) in (2, 10):
+                points = torch.from_dlpack(points)
+            else:
+                points = np.from_dlpack(points)
         if _is_torch(points):
             import torch
             t = points

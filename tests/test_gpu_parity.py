@@ -267,6 +267,36 @@ def test_device_pointer_entry_points_with_torch():
     assert (s.nn(pts).cpu().numpy() == o.nn(h)).all()
 
 
+def test_dlpack_device_arrays_reach_the_device_entry_points():
+    """a non-torch DLPack producer (stand-in: an object exposing only __dlpack__ / __dlpack_device__) holding
+    device memory is answered on the device, without a host round trip, and equals the numpy path"""
+    import torch
+
+    class Capsule:  # what CuPy / JAX arrays look like to a consumer
+        def __init__(self, t):
+            self._t = t
+
+        def __dlpack__(self, stream=None, **kw):
+            return self._t.__dlpack__()
+
+        def __dlpack_device__(self):
+            return self._t.__dlpack_device__()
+
+    v, f = meshes.torus(60, 60)
+    s = SDF(v, f)
+    s.set_raycast_axes(meshes.random_rotation(2))
+    pts = np.random.default_rng(4).uniform(-1, 1, (60_000, 3)).astype(np.float32)
+    t = torch.from_numpy(pts).cuda()
+    d, c, n = s(Capsule(t)), s.contains(Capsule(t)), s.nn(Capsule(t))
+    assert d.is_cuda and c.is_cuda and n.is_cuda
+    assert same_float(d.cpu().numpy(), s(pts)).all()
+    assert (c.cpu().numpy() == s.contains(pts)).all() and (n.cpu().numpy() == s.nn(pts)).all()
+    back = torch.from_dlpack(d)  # the result is itself a DLPack producer
+    assert back.data_ptr() == d.data_ptr()
+    h = s(Capsule(torch.from_numpy(pts)))  # a host DLPack array takes the numpy path
+    assert isinstance(h, np.ndarray) and same_float(h, s(pts)).all()
+
+
 def test_async_queries_on_two_streams_and_update_do_not_race():
     """`_device` calls are asynchronous on the caller's stream and share the handle's workspace:
     a call on a second stream and update() must be ordered after the kernels of the call before."""

@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
-"""Small-batch latency of the host entry points (numpy in, numpy out), pybench.py-sized calls."""
+"""Small-batch latency of the host entry points (numpy in, numpy out), pybench.py-sized calls, with and without the exact scan."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/sdf_amd") else os.getcwd())
+sys.path.insert(0, os.getcwd())
 import sdf_amd
 from sdf_amd import meshes
-g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "golden_teapot.npz"))
-for name, (v, f) in (("teapot", (g["verts"], g["faces"])), ("torus424", meshes.torus(424, 424))):
-    s = sdf_amd.SDF(v, f)
-    for n in (1, 1000, 100_000, 1_000_000):
-        p = np.random.default_rng(0).standard_normal((n, 3)).astype(np.float32) * 0.5
-        for fn_name, fn in (("sdf", s.__call__), ("contains", s.contains), ("nn", s.nn)):
-            for _ in range(3): fn(p)
-            ts = []
-            for _ in range(20):
-                t0 = time.perf_counter(); fn(p); ts.append(time.perf_counter() - t0)
-            print(f"{name:9s} n={n:8d} {fn_name:9s} median {np.median(ts)*1e6:9.1f} us  min {min(ts)*1e6:9.1f} us", flush=True)
+v, f = meshes.torus(424, 424)
+s = sdf_amd.SDF(v, f)
+s.set_option("profile", 1)
+for n in (1000, 100_000, 1_000_000):
+    for dist in ("randn", "uniform"):
+        rng = np.random.default_rng(0)
+        p = (rng.standard_normal((n, 3)) * 0.5 if dist == "randn" else rng.uniform(-1, 1, (n, 3))).astype(np.float32)
+        for _ in range(3): s.nn(p)
+        s.set_option("profile", 2)
+        t0 = time.perf_counter(); s.nn(p); dt = time.perf_counter() - t0
+        st = s.stats
+        print(f"n={n} {dist}: {dt*1e6:.0f} us  fallback {st['last_fallback_points']} heavy {st['last_heavy_points']} packet-kernel {st['query_kernel_ms']:.3f} ms")
