@@ -305,6 +305,9 @@ __device__ __forceinline__ void group_exact(const MeshDev& M, float qx, float qy
 }
 
 // approximate evaluation (see "Approximate first pass" below): group minimum of a(), sorted insert
+// DEDUPE (continuation of a walk by the cooperative kernel): a lane that already lists `cur` among its first
+// three groups keeps its list (the group was evaluated before the hand-over).
+template <bool DEDUPE>
 __device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y2, float Z2, uint32_t cur,
                                              ApproxState& S) {
     const uint32_t nch = cur & 15u;
@@ -345,6 +348,7 @@ __device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y
 #undef SDFK_APX_SLOT
     // sorted insert of this group's minimum into B1..B4 (+ the groups of the first three);
     // skipped when no lane's top four change (the insert is then the identity)
+    if (DEDUPE && (cur == S.H1 || cur == S.H2 || cur == S.H3)) gm = __builtin_inff();
     if (__ballot(gm < S.B4) != 0ull) {
         const bool c1 = gm < S.B1, c2 = gm < S.B2, c3 = gm < S.B3;
         S.H3 = c2 ? S.H2 : (c3 ? cur : S.H3);
@@ -384,9 +388,14 @@ __device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y
 
 // The walk itself.  APPROX: SA is updated (thresholds from upper(B1) * c^2 = max(B1 + Qe, 0) * cm),
 // else SE (thresholds b * c^2).  Returns true when the wave gave up (work budget, see k_query_heavy).
-template <bool APPROX>
+// CONT (cooperative kernel, APPROX only): SA holds the state of a walk that passed M.coop_budget in the main
+// kernel; this wave continues it over the L1 nodes j with j % nparts == part (the walk is redone from the
+// first L1 node with the saved, nearly final thresholds: groups met again are recognised per lane).
+// budget: work units (chunks evaluated + candidates tested) after which the wave gives up.
+template <bool APPROX, bool CONT>
 __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy, float qz, float Qe, float cm,
-                                            ExactState& SE, ApproxState& SA) {
+                                            ExactState& SE, ApproxState& SA, uint32_t part, uint32_t nparts,
+                                            uint32_t budget) {
     const uint32_t lane = threadIdx.x & 63u;
     SDFK_COUNT(0, 1);
     if (M.kd_ngroups == 0u) return false;
@@ -422,7 +431,7 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
         work += (REF) & 15u;                                                              \
         const uint32_t old_ = APPROX ? __float_as_uint(SA.B1) : SE.b;                     \
         if (APPROX)                                                                       \
-            group_approx(M, X2, Y2, Z2, (REF), SA);                                       \
+            group_approx<CONT>(M, X2, Y2, Z2, (REF), SA);                                 \
         else                                                                              \
             group_exact(M, qx, qy, qz, (REF), SE);                                        \
         moved = __ballot(old_ != (APPROX ? __float_as_uint(SA.B1) : SE.b)) != 0ull;       \
@@ -452,7 +461,11 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
         const uint32_t mk = wave_umin(key);
         g0 = (uint32_t)__builtin_ctzll(__ballot(key == mk));
         const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)o.tag, (int)g0);
-        SDFK_PK_EVAL(ref)
+        if (CONT) {  // evaluated before the hand-over: only the thresholds are needed
+            SDFK_PK_REFRESH()
+        } else {
+            SDFK_PK_EVAL(ref)
+        }
         // Across the packet the thresholds follow the distance field, rr_l ~ r0 + g.e_l with g the
         // direction away from the nearest patch: the packet-level tests bound rr_l - g.e_l instead of
         // rr_l alone (any g is valid; this one makes the residual small in the far field).
@@ -478,7 +491,7 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
         const ObbLane o1 = obb_wide<true>(M.kd_l1obb + 256u * (size_t)row, lane, cx, cy, cz, Ew, gx, gy, gz, hx, hy, hz);
         SDFK_COUNT(1, 1);
         float res = SDFK_PK_RES();
-        bool alive1 = 64u * row + lane < M.kd_nl1 && !(o1.pk > res);
+        bool alive1 = 64u * row + lane < M.kd_nl1 && !(o1.pk > res) && (!CONT || (64u * row + lane) % nparts == part);
         unsigned long long m1 = __ballot(alive1);
         for (;;) {
             uint32_t k;
@@ -521,7 +534,7 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
                 if (__ballot(!(t > rr)) == 0ull) continue;
                 const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)o.tag, (int)g);
                 SDFK_PK_EVAL(ref)
-                if (work > M.heavy_budget) return true;  // give up (wave-uniform): k_query_heavy takes over
+                if (work > budget) return true;  // give up (wave-uniform): the cooperative kernel / k_query_heavy takes over
                 if (moved) res = SDFK_PK_RES();  // tightened
             }
         }
@@ -618,65 +631,40 @@ __device__ __forceinline__ float kd_path_max_bound(const MeshDev& M, float qx, f
     return worst_bound;
 }
 
+// every valid query of this wave goes to the heavy list (absolute indices); wave-uniform
+__device__ __forceinline__ void packet_to_heavy(bool valid, int64_t i, int64_t src, uint32_t off,
+                                                unsigned long long* __restrict__ amb_mask, uint32_t* __restrict__ amb_cnt,
+                                                uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt) {
+    const unsigned long long vm = __ballot(valid);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0) {
+        base = atomicAdd(heavy_cnt, (uint32_t)__popcll(vm));
+        amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (valid) heavy_list[base + (uint32_t)__popcll(vm & lt)] = off + (uint32_t)src;
+}
+
+// error model of a() for one lane (see "Approximate first pass")
+__device__ __forceinline__ void approx_model(const MeshDev& M, V3 p, float& Qf, float& Ea) {
+    const float u = 5.9604645e-8f;  // 2^-24
+    const float Vx = fmaxf(fabsf(M.bb[0]), fabsf(M.bb[3])), Vy = fmaxf(fabsf(M.bb[1]), fabsf(M.bb[4])),
+                Vz = fmaxf(fabsf(M.bb[2]), fabsf(M.bb[5]));
+    const float S = M.vmax2 + 2.f * ((fabsf(p.x) * Vx + fabsf(p.y) * Vy) + fabsf(p.z) * Vz);
+    Qf = (p.x * p.x + p.y * p.y) + p.z * p.z;
+    Ea = u * (5.f * S + 4.f * Qf);
+}
+
+// What follows the walk, per lane: the exact second phase (APPROX), the decision whether the walk's answer
+// is nanoflann's, and the result (nearest vertex / incident-face distances / sign).
 template <int KIND, bool ROBUST, bool APPROX>
-__global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M, const float* __restrict__ pts,
-                                                         const uint32_t* __restrict__ perm, int64_t n,
-                                                         int trunc_aabb, void* __restrict__ out,
-                                                         unsigned long long* __restrict__ amb_mask,
-                                                         uint32_t* __restrict__ amb_cnt,
-                                                         uint32_t off,
-                                                         uint32_t* __restrict__ heavy_list,
-                                                         uint32_t* __restrict__ heavy_cnt) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i < n;
-    // lanes past the end of the batch repeat its last query (and write nothing): they then ask
-    // for no subtree a real lane does not
-    const int64_t ic = valid ? i : n - 1;
-    // the point stream (and the results) pass through once: non-temporal, so that L2 keeps the trees
-    const int64_t src = perm ? (int64_t)SDFK_NT_LOAD(&perm[ic]) : ic;
-    const V3 p = {SDFK_NT_LOAD(&pts[3 * src]), SDFK_NT_LOAD(&pts[3 * src + 1]), SDFK_NT_LOAD(&pts[3 * src + 2])};
-    float sign = 0.f;
-    if (ROBUST && KIND != Q_NN) sign = raycast_packet(M, p, valid);  // sdf.cpp:110
-    if (ROBUST && KIND == Q_CONTAINS) {  // sdf.cpp:163-169: no nearest-vertex search at all
-        if (valid) ((uint8_t*)out)[src] = sign >= 0.0f;
-        if ((threadIdx.x & 63) == 0) amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
-        return;
-    }
-    PacketBest pb;
-    ExactState SE = {0x7F7FFFFFu, 0x7F7FFFFFu, H_NONE, 0xFFFFFFFFu};  // FLT_MAX bits (KNNResultSet::init)
-    const float INF = __builtin_inff();
-    ApproxState A = {INF, INF, INF, INF, H_NONE, H_NONE, H_NONE};
-    float Qf = 0.f, Ea = 0.f;
-    if (APPROX) {
-        // error model of a() for this lane (see "Approximate first pass")
-        const float u = 5.9604645e-8f;  // 2^-24
-        const float Vx = fmaxf(fabsf(M.bb[0]), fabsf(M.bb[3])), Vy = fmaxf(fabsf(M.bb[1]), fabsf(M.bb[4])),
-                    Vz = fmaxf(fabsf(M.bb[2]), fabsf(M.bb[5]));
-        const float S = M.vmax2 + 2.f * ((fabsf(p.x) * Vx + fabsf(p.y) * Vy) + fabsf(p.z) * Vz);
-        Qf = (p.x * p.x + p.y * p.y) + p.z * p.z;
-        Ea = u * (5.f * S + 4.f * Qf);
-        pb.bailed = packet_walk<true>(M, p.x, p.y, p.z, Qf + Ea, (1.f + 8.f * u) * M.amb_c2, SE, A);
-    } else {
-        pb.bailed = packet_walk<false>(M, p.x, p.y, p.z, 0.f, 1.f, SE, A);
-        if (SE.b == SE.tieb) SE.s2 = SE.b;  // a settled exact tie is a tie
-        pb.b = __uint_as_float(SE.b), pb.s = __uint_as_float(SE.s2), pb.h = SE.h;
-    }
-    if (pb.bailed) {  // wave-uniform: every query of this wave goes to the heavy list (absolute indices)
-        const unsigned long long vm = __ballot(valid);
-        const uint32_t lane = threadIdx.x & 63u;
-        uint32_t base = 0;
-        if (lane == 0) {
-            base = atomicAdd(heavy_cnt, (uint32_t)__popcll(vm));
-            amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
-        }
-        base = __builtin_amdgcn_readfirstlane(base);
-        const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-        if (valid) heavy_list[base + (uint32_t)__popcll(vm & lt)] = off + (uint32_t)src;
-        return;
-    }
-#if SDFK_EXP == 2 || SDFK_EXP == 3
-    if (KIND == Q_NN) { if (valid) ((int32_t*)out)[src] = APPROX ? (int)A.H1 : (int)SE.h; if ((threadIdx.x & 63) == 0) amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u; return; }
-#endif
+__device__ __forceinline__ void packet_finish(const MeshDev& M, V3 p, bool valid, int64_t i, int64_t src, float sign,
+                                              PacketBest pb, const ApproxState& A, float Qf, float Ea, int trunc_aabb,
+                                              void* __restrict__ out, unsigned long long* __restrict__ amb_mask,
+                                              uint32_t* __restrict__ amb_cnt, uint32_t off,
+                                              uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt) {
     // pb.h is nanoflann's answer iff nanoflann does not prune it before visiting it:
     //  (1) no other vertex within b * c (c - 1 ~ 4.5e-6): impossible, see k_query_packet header;
     //  (2) otherwise measure it: every bound tested on the way to pb.h is <= the distance of
@@ -747,6 +735,157 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
     }
 }
 
+// Hand-over to the cooperative kernel: packet index + the per-lane lists of the walk so far.
+constexpr int COOP_WAVES = 8;
+struct CoopBuf {
+    uint32_t* list;   // [cap] packet (wave) index within the launch
+    uint32_t* state;  // [cap][7][64]: B1..B4 (float bits), H1..H3
+    uint32_t* count;  // packets handed over (may exceed cap: those went to the heavy list instead)
+    uint32_t cap;     // 0: no cooperative kernel
+};
+
+template <int KIND, bool ROBUST, bool APPROX>
+__global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M, const float* __restrict__ pts,
+                                                         const uint32_t* __restrict__ perm, int64_t n,
+                                                         int trunc_aabb, void* __restrict__ out,
+                                                         unsigned long long* __restrict__ amb_mask,
+                                                         uint32_t* __restrict__ amb_cnt,
+                                                         uint32_t off,
+                                                         uint32_t* __restrict__ heavy_list,
+                                                         uint32_t* __restrict__ heavy_cnt, CoopBuf CB) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    // lanes past the end of the batch repeat its last query (and write nothing): they then ask
+    // for no subtree a real lane does not
+    const int64_t ic = valid ? i : n - 1;
+    // the point stream (and the results) pass through once: non-temporal, so that L2 keeps the trees
+    const int64_t src = perm ? (int64_t)SDFK_NT_LOAD(&perm[ic]) : ic;
+    const V3 p = {SDFK_NT_LOAD(&pts[3 * src]), SDFK_NT_LOAD(&pts[3 * src + 1]), SDFK_NT_LOAD(&pts[3 * src + 2])};
+    float sign = 0.f;
+    if (ROBUST && KIND != Q_NN) sign = raycast_packet(M, p, valid);  // sdf.cpp:110
+    if (ROBUST && KIND == Q_CONTAINS) {  // sdf.cpp:163-169: no nearest-vertex search at all
+        if (valid) ((uint8_t*)out)[src] = sign >= 0.0f;
+        if ((threadIdx.x & 63) == 0) amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
+        return;
+    }
+    PacketBest pb;
+    ExactState SE = {0x7F7FFFFFu, 0x7F7FFFFFu, H_NONE, 0xFFFFFFFFu};  // FLT_MAX bits (KNNResultSet::init)
+    const float INF = __builtin_inff();
+    ApproxState A = {INF, INF, INF, INF, H_NONE, H_NONE, H_NONE};
+    float Qf = 0.f, Ea = 0.f;
+    const bool coop = APPROX && CB.cap != 0u;
+    if (APPROX) {
+        approx_model(M, p, Qf, Ea);
+        pb.bailed = packet_walk<true, false>(M, p.x, p.y, p.z, Qf + Ea, (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A, 0u,
+                                             1u, coop ? M.coop_budget : M.heavy_budget);
+    } else {
+        pb.bailed = packet_walk<false, false>(M, p.x, p.y, p.z, 0.f, 1.f, SE, A, 0u, 1u, M.heavy_budget);
+        if (SE.b == SE.tieb) SE.s2 = SE.b;  // a settled exact tie is a tie
+        pb.b = __uint_as_float(SE.b), pb.s = __uint_as_float(SE.s2), pb.h = SE.h;
+    }
+    if (pb.bailed) {  // wave-uniform
+        uint32_t slot = 0xFFFFFFFFu;
+        if (coop) {
+            if ((threadIdx.x & 63) == 0) slot = atomicAdd(CB.count, 1u);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+        }
+        if (slot < CB.cap) {  // the walk goes on in k_query_packet_coop, from these lists
+            const uint32_t lane = threadIdx.x & 63u;
+            uint32_t* st = CB.state + (size_t)slot * 448u + lane;
+            st[0] = __float_as_uint(A.B1), st[64] = __float_as_uint(A.B2), st[128] = __float_as_uint(A.B3);
+            st[192] = __float_as_uint(A.B4), st[256] = A.H1, st[320] = A.H2, st[384] = A.H3;
+            if (lane == 0) {
+                CB.list[slot] = (uint32_t)(i >> 6);
+                amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
+            }
+        } else {
+            packet_to_heavy(valid, i, src, off, amb_mask, amb_cnt, heavy_list, heavy_cnt);
+        }
+        return;
+    }
+    packet_finish<KIND, ROBUST, APPROX>(M, p, valid, i, src, sign, pb, A, Qf, Ea, trunc_aabb, out, amb_mask, amb_cnt, off,
+                                        heavy_list, heavy_cnt);
+}
+
+// The packets whose walk passed M.coop_budget in the main kernel (queries near a centre of symmetry of the
+// mesh need a large part of the tree; one wave doing that alone is the tail of the whole launch): COOP_WAVES
+// waves share one packet.  Every wave holds the same 64 queries and the lists saved at the hand-over — so its
+// thresholds are nearly final from the start — and redoes the walk over the L1 nodes j with
+// j % COOP_WAVES == wave; a group met again is recognised per lane by its ref.  The lists of the waves are
+// merged through LDS (sorted inserts; refs already listed are skipped; a wave's fourth minimum only bounds
+// what lies outside the first three) and wave 0 finishes the queries.  A wave that passes a quarter of the
+// hard budget (8 waves: twice the work the main kernel alone would spend) sends the whole packet to the
+// exact scan (k_query_heavy), as the main kernel does without this one: the few packets at a centre of
+// symmetry need every group, and each wave running to the full budget made this kernel 1.1 ms long.
+template <int KIND, bool ROBUST>
+__global__ __launch_bounds__(64 * COOP_WAVES) SDFK_PK_SGPR void k_query_packet_coop(
+    MeshDev M, const float* __restrict__ pts, const uint32_t* __restrict__ perm, int64_t n, int trunc_aabb,
+    void* __restrict__ out, unsigned long long* __restrict__ amb_mask, uint32_t* __restrict__ amb_cnt, uint32_t off,
+    uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, CoopBuf CB) {
+    __shared__ uint32_t sS[COOP_WAVES][7][64];
+    __shared__ uint32_t s_over;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t cnt = min(*CB.count, CB.cap);
+    for (uint32_t e = blockIdx.x; e < cnt; e += gridDim.x) {  // block-uniform
+        if (threadIdx.x == 0) s_over = 0u;
+        __syncthreads();
+        const int64_t i = (int64_t)CB.list[e] * 64 + lane;
+        const bool valid = i < n;
+        const int64_t ic = valid ? i : n - 1;
+        const int64_t src = perm ? (int64_t)perm[ic] : ic;
+        const V3 p = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
+        ExactState SE = {0x7F7FFFFFu, 0x7F7FFFFFu, H_NONE, 0xFFFFFFFFu};
+        const uint32_t* st = CB.state + (size_t)e * 448u + lane;
+        ApproxState A = {__uint_as_float(st[0]),   __uint_as_float(st[64]), __uint_as_float(st[128]),
+                         __uint_as_float(st[192]), st[256],                 st[320],
+                         st[384]};
+        float Qf, Ea;
+        approx_model(M, p, Qf, Ea);
+        const bool over = packet_walk<true, true>(M, p.x, p.y, p.z, Qf + Ea, (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A,
+                                                  wave, (uint32_t)COOP_WAVES, max(M.coop_budget, M.heavy_budget / 4u));
+        if (over && lane == 0) atomicOr(&s_over, 1u);
+        if (wave != 0) {
+            sS[wave][0][lane] = __float_as_uint(A.B1), sS[wave][1][lane] = __float_as_uint(A.B2);
+            sS[wave][2][lane] = __float_as_uint(A.B3), sS[wave][3][lane] = __float_as_uint(A.B4);
+            sS[wave][4][lane] = A.H1, sS[wave][5][lane] = A.H2, sS[wave][6][lane] = A.H3;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            if (s_over) {
+                packet_to_heavy(valid, i, src, off, amb_mask, amb_cnt, heavy_list, heavy_cnt);
+            } else {
+                for (int w = 1; w < COOP_WAVES; ++w) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float gm = __uint_as_float(sS[w][k][lane]);
+                        const uint32_t ref = sS[w][4 + k][lane];
+                        if (ref == H_NONE || ref == A.H1 || ref == A.H2 || ref == A.H3) continue;
+                        const bool c1 = gm < A.B1, c2 = gm < A.B2, c3 = gm < A.B3;
+                        A.H3 = c2 ? A.H2 : (c3 ? ref : A.H3);
+                        A.H2 = c1 ? A.H1 : (c2 ? ref : A.H2);
+                        A.H1 = c1 ? ref : A.H1;
+                        float t = fmaxf(A.B1, gm);
+                        A.B1 = fminf(A.B1, gm);
+                        float t2 = fmaxf(A.B2, t);
+                        A.B2 = fminf(A.B2, t);
+                        t = fmaxf(A.B3, t2);
+                        A.B3 = fminf(A.B3, t2);
+                        A.B4 = fminf(A.B4, t);
+                    }
+                    // (>= the merged third minimum: the global third is <= any wave's third <= its fourth)
+                    A.B4 = fminf(A.B4, __uint_as_float(sS[w][3][lane]));
+                }
+                float sign = 0.f;
+                if (ROBUST && KIND != Q_NN) sign = raycast_packet(M, p, valid);
+                PacketBest pb;
+                pb.bailed = false;
+                packet_finish<KIND, ROBUST, true>(M, p, valid, i, src, sign, pb, A, Qf, Ea, trunc_aabb, out, amb_mask,
+                                                  amb_cnt, off, heavy_list, heavy_cnt);
+            }
+        }
+        __syncthreads();  // LDS is reused by the next packet
+    }
+}
 
 // amb_cnt has been exclusive-scanned: wave w's ambiguous queries go to fb_list[amb_cnt[w] ...]
 // The list accumulates over the chunks of one call (entries are absolute point indices):

@@ -31,6 +31,7 @@ struct MeshDev {
     const float4* kd_pts4;
     uint32_t kd_npos;       // padded tree positions (sentinel slots included)
     uint32_t heavy_budget;  // packet pass: a wave that has evaluated more chunks than this gives up
+    uint32_t coop_budget;   // ... and hands its packet to the cooperative kernel past this many (approximate walk)
     float amb_c, amb_c2;
     float vmax2;  // max |v|^2 (approximate first pass)
     // adjacency + face geometry

@@ -130,6 +130,8 @@ struct GridBuf {
 
 // Device workspace of one query call: Morton keys / permutation of the query sort (+ the sorter's
 // alternates and histograms), the per-wave masks of deferred queries, the deferred / heavy lists.
+constexpr uint32_t COOP_CAP = 16384;  // packets one launch can hand to k_query_packet_coop (28 MiB of lists)
+
 struct QueryWs {
     uint32_t* qkeys = nullptr;
     uint32_t* qperm = nullptr;
@@ -139,7 +141,10 @@ struct QueryWs {
     uint32_t* amb_s1 = nullptr;
     uint32_t* amb_s2 = nullptr;
     uint32_t* fb_list = nullptr;   // [0, cap): deferred near-tie queries; [cap, 2 cap): heavy-wave queries
-    uint32_t* fb_count = nullptr;  // [0], [1] length of the deferred list (ping-pong, see k_fb_compact), [2] heavy list
+    uint32_t* fb_count = nullptr;  // [0], [1] length of the deferred list (ping-pong, see k_fb_compact), [2] heavy list,
+                                   // [3] packets handed to the cooperative kernel
+    uint32_t* coop_list = nullptr;   // [COOP_CAP] (null in the static scratch: no cooperative kernel there)
+    uint32_t* coop_state = nullptr;  // [COOP_CAP][7][64]
     int64_t q_cap = 0, fb_cap = 0;
     RadixSorter sorter;
     bool fixed = false;  // carved out of the static scratch array: never grown, never freed
@@ -182,6 +187,8 @@ struct sdfhip_ctx {
     uint32_t* h_counts = nullptr;  // page-locked: [0] length of the last deferred list, [1] queries of the
                                    // last call's heavy waves (read back only while profiling)
     int64_t opt_heavy_budget = 0;  // chunks per wave before it gives up; 0 = automatic
+    int64_t opt_coop_budget = 1500;  // work units after which a packet goes on in the cooperative kernel; 0 = never
+    int64_t opt_coop_max = 8 << 20;  // launches of more points than this keep their long waves
     int64_t opt_scan_max = -1;  // n x positions up to which a batch is answered by the exact scan; -1 = automatic
     int64_t opt_packet = 1;
     int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
@@ -772,6 +779,7 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     // a wave may walk 1/8 of the tree (4 positions per chunk) before it hands its queries over
     M.heavy_budget = h->opt_heavy_budget > 0 ? (uint32_t)h->opt_heavy_budget
                                              : (M.kd_npos / 32u > 4096u ? M.kd_npos / 32u : 4096u);
+    M.coop_budget = (uint32_t)std::min<int64_t>(h->opt_coop_budget, M.heavy_budget);
     M.amb_c = h->amb_c;
     M.vmax2 = h->vmax2;
     M.amb_c2 = h->amb_c2;
@@ -873,6 +881,10 @@ int reserve_query_ws(sdfhip_ctx* h, int64_t n, int64_t fb_cap) {
         if (int rc = dalloc(&W.amb_s2, nw / 2048 / 2048 + 4)) return rc;
         if (!W.qbounds)
             if (int rc = dalloc(&W.qbounds, 8)) return rc;
+        if (!W.coop_list) {
+            if (int rc = dalloc(&W.coop_list, (size_t)COOP_CAP)) return rc;
+            if (int rc = dalloc(&W.coop_state, (size_t)COOP_CAP * 448)) return rc;
+        }
         W.q_cap = n;
     }
     if (fb_cap > W.fb_cap) {
@@ -919,7 +931,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     if (needs_nn && M.kd_npos > 0 && n <= 0x7FFFFFFF && (double)n * (double)M.kd_npos <= scan_max) {
         if (int rc = reserve_query_ws(h, 0, n)) return rc;
         constexpr int HK = needs_nn ? KIND : Q_NN;
-        HIPC(hipMemsetAsync(W.fb_count, 0, 3 * sizeof(uint32_t), s));
+        HIPC(hipMemsetAsync(W.fb_count, 0, 4 * sizeof(uint32_t), s));
         const int64_t packs = (n + HEAVY_Q - 1) / HEAVY_Q;
         // kinds with a tail: positions first, then one lane per query for ray parity + face distances
         int32_t* pos = KIND == Q_NN ? nullptr : (int32_t*)(W.fb_list + W.fb_cap);
@@ -956,7 +968,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     int64_t deferred_pts = 0;  // points whose near ties may sit in the deferred list
     int flip = 0;              // d_fb_count[flip] holds the current list length
     // d_fb_count: [0], [1] length of the deferred list (ping-pong), [2] length of the heavy list
-    if (packet_any) HIPC(hipMemsetAsync(W.fb_count, 0, 3 * sizeof(uint32_t), s));
+    if (packet_any) HIPC(hipMemsetAsync(W.fb_count, 0, 4 * sizeof(uint32_t), s));
     auto flush = [&]() -> int {
         if (deferred_pts == 0) return 0;
         constexpr int HK = (KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST)) ? Q_NN : KIND;
@@ -990,7 +1002,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             HIPC(hipMemcpyAsync(&h->h_counts[0], W.fb_count + flip, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIPC(hipMemcpyAsync(&h->h_counts[1], W.fb_count + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         }
-        HIPC(hipMemsetAsync(W.fb_count, 0, 3 * sizeof(uint32_t), s));
+        HIPC(hipMemsetAsync(W.fb_count, 0, 4 * sizeof(uint32_t), s));
         flip = 0;
         deferred_pts = 0;
         return 0;
@@ -1024,14 +1036,28 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             // tree of fast_nn has no strict kernel behind it and keeps the exact walk
             const bool approx = !fast && (h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0);
             h->last_kernel = approx ? SDFHIP_KERNEL_PACKET_APPROX : SDFHIP_KERNEL_PACKET_EXACT;
+            // Long walks go on in the cooperative kernel (8 waves per packet); not for ray-only contains().
+            // It is one more serial phase (~0.4 ms): it pays while the launch is short enough for its few long
+            // waves to be the tail (nn 4M 2.68 -> 2.26 ms), not when they overlap the rest of a long launch
+            // anyway (256^3 grid in one launch: 3.67 -> 3.78 ms).
+            const bool coop = approx && M.coop_budget != 0u && W.coop_list && !(ROBUST && KIND == Q_CONTAINS) &&
+                              m <= h->opt_coop_max;
+            const CoopBuf CB = {W.coop_list, W.coop_state, W.fb_count + 3, coop ? COOP_CAP : 0u};
             if (approx)
                 k_query_packet<PK, ROBUST, true><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, 0, s>>>(
                     M, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
-                    W.fb_list + W.fb_cap, W.fb_count + 2);
+                    W.fb_list + W.fb_cap, W.fb_count + 2, CB);
             else
                 k_query_packet<PK, ROBUST, false><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, 0, s>>>(
                     M, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
-                    W.fb_list + W.fb_cap, W.fb_count + 2);
+                    W.fb_list + W.fb_cap, W.fb_count + 2, CB);
+            if (coop) {
+                const int64_t npk = (m + 63) / 64;
+                k_query_packet_coop<PK, ROBUST><<<(uint32_t)(npk < 1024 ? npk : 1024), 64 * COOP_WAVES, 0, s>>>(
+                    M, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
+                    W.fb_list + W.fb_cap, W.fb_count + 2, CB);
+                HIPC(hipMemsetAsync(W.fb_count + 3, 0, sizeof(uint32_t), s));
+            }
             if (int rc = prof.end(m)) return rc;
             if (fast) {  // no near-tie deferral in this mode, only the heavy list
                 HIPC(hipGetLastError());
@@ -1423,7 +1449,7 @@ void sdfhip_destroy(sdfhip_t* h) {
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
                     h->topo.depthI, h->ws.qkeys, h->ws.qperm, h->ws.qbounds, h->d_gstack, h->d_kd_pts4,
-                    h->ws.fb_list, h->ws.fb_count, h->ws.amb_mask, h->ws.amb_cnt, h->ws.amb_s1, h->ws.amb_s2,
+                    h->ws.fb_list, h->ws.fb_count, h->ws.coop_list, h->ws.coop_state, h->ws.amb_mask, h->ws.amb_cnt, h->ws.amb_s1, h->ws.amb_s2,
                     h->d_vkeys, h->d_vidx};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1717,6 +1743,12 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
     else if (!strcmp(key, "heavy_budget")) {
         if (v < 0 || v > 0x7FFFFFFF) return fail(SDFHIP_E_INVALID, "heavy_budget must be >= 0 (0 = automatic)");
         h->opt_heavy_budget = v;
+    } else if (!strcmp(key, "coop_budget")) {
+        if (v < 0 || v > 0x7FFFFFFF) return fail(SDFHIP_E_INVALID, "coop_budget must be >= 0 (0 = no cooperative kernel)");
+        h->opt_coop_budget = v;
+    } else if (!strcmp(key, "coop_max")) {
+        if (v < 0) return fail(SDFHIP_E_INVALID, "coop_max must be >= 0");
+        h->opt_coop_max = v;
     } else if (!strcmp(key, "fast_nn"))
         h->opt_fast_nn = v ? 1 : 0;  // takes effect at the next sdfhip_update
     else if (!strcmp(key, "ray_mode")) {

@@ -497,6 +497,41 @@ def test_heavy_wave_path_forced(budget):
     assert same_float(sn(p), on(p)).all() and (sn.contains(p) == on.contains(p)).all()
 
 
+@pytest.mark.parametrize("budget", [4, 60])
+def test_cooperative_continuation_forced(budget):
+    """k_query_packet_coop: with a tiny hand-over budget (nearly) every packet's walk is finished by eight
+    waves from the saved lists and merged; the hard budget stays automatic, so the answers come from
+    that kernel and not from the exact scan.  Same bits as the oracle: ties, near ties, sdf tail."""
+    rng = np.random.default_rng(22)
+    g = np.stack(np.meshgrid(*[np.arange(-6, 7)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    v = (g[rng.permutation(g.shape[0])[:1500]] * 0.125).astype(np.float32)
+    v = np.concatenate([v, v[:40]])
+    f = np.array([[0, 1, 2], [3, 4, 5]], np.uint32)
+    q = np.concatenate([(rng.integers(-14, 15, (30000, 3)) * 0.0625), rng.uniform(-1, 1, (20000, 3)),
+                        v[rng.integers(0, v.shape[0], 3000)]]).astype(np.float32)
+    o = po.OracleSDF(v, f, False)
+    s = SDF(v, f, robust=False)
+    for key, val in (("approx", 1), ("coop_budget", budget), ("profile", 1)):
+        s.set_option(key, val)
+    assert (s.nn(q) == o.nn(q)).all()
+    assert s.stats["last_heavy_points"] < q.shape[0] // 4
+    assert same_float(s(q), o(q)).all()
+    v, f = meshes.torus(120, 120)
+    R = meshes.random_rotation(10)
+    o = po.OracleSDF(v, f, True, R)
+    s = SDF(v, f)
+    s.set_raycast_axes(R)
+    for key, val in (("approx", 1), ("coop_budget", budget)):
+        s.set_option(key, val)
+    p = np.concatenate([rng.uniform(-1, 1, (80000, 3)), meshes.grid_points(30),
+                        rng.normal(0, 1e-5, (3000, 3))]).astype(np.float32)
+    want_nn, want = o.nn(p), o(p)
+    assert (s.nn(p) == want_nn).all()
+    assert same_float(s(p), want).all() and same_float(s(p, True), o(p, True)).all()
+    s.set_option("coop_budget", 0)  # and without the kernel
+    assert (s.nn(p) == want_nn).all() and same_float(s(p), want).all()
+
+
 def test_sphere_centre_queries_take_the_heavy_path():
     """icosphere: queries near the centre need (nearly) every vertex; with the automatic budget
     their waves give up and the heavy kernel answers — same bits as the oracle."""
