@@ -534,7 +534,7 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
                 if (__ballot(!(t > rr)) == 0ull) continue;
                 const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)o.tag, (int)g);
                 SDFK_PK_EVAL(ref)
-                if (work > budget) return true;  // give up (wave-uniform): the cooperative kernel / k_query_heavy takes over
+                if (work > (CONT ? budget : M.heavy_budget)) return true;  // give up (wave-uniform): the cooperative kernel / k_query_heavy takes over
                 if (moved) res = SDFK_PK_RES();  // tightened
             }
         }
@@ -736,12 +736,16 @@ __device__ __forceinline__ void packet_finish(const MeshDev& M, V3 p, bool valid
 }
 
 // Hand-over to the cooperative kernel: packet index + the per-lane lists of the walk so far.
+// The main kernel must not pay for it in registers (two more VGPRs took it from 7 to 6 waves per SIMD and
+// the 125M-point step from 23.5 to 24.5 ms): it gets no argument for it.  The switch is the low bit of
+// M.heavy_budget (odd: hand over to the cooperative kernel at that budget; the host sets it per launch),
+// the counter is the word after the heavy counter and the two pointers sit in device memory behind
+// it (CoopDesc at heavy_cnt + 2, written once by the host), read only by the waves that hand over.
 constexpr int COOP_WAVES = 8;
-struct CoopBuf {
-    uint32_t* list;   // [cap] packet (wave) index within the launch
-    uint32_t* state;  // [cap][7][64]: B1..B4 (float bits), H1..H3
-    uint32_t* count;  // packets handed over (may exceed cap: those went to the heavy list instead)
-    uint32_t cap;     // 0: no cooperative kernel
+constexpr uint32_t COOP_CAP = 16384;  // packets one launch can hand over (28 MiB of lists)
+struct CoopDesc {
+    uint32_t* list;   // [COOP_CAP] packet (wave) index within the launch
+    uint32_t* state;  // [COOP_CAP][7][64]: B1..B4 (float bits), H1..H3
 };
 
 template <int KIND, bool ROBUST, bool APPROX>
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
                                                          uint32_t* __restrict__ amb_cnt,
                                                          uint32_t off,
                                                          uint32_t* __restrict__ heavy_list,
-                                                         uint32_t* __restrict__ heavy_cnt, CoopBuf CB) {
+                                                         uint32_t* __restrict__ heavy_cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     // lanes past the end of the batch repeat its last query (and write nothing): they then ask
@@ -773,11 +777,10 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
     const float INF = __builtin_inff();
     ApproxState A = {INF, INF, INF, INF, H_NONE, H_NONE, H_NONE};
     float Qf = 0.f, Ea = 0.f;
-    const bool coop = APPROX && CB.cap != 0u;
     if (APPROX) {
         approx_model(M, p, Qf, Ea);
         pb.bailed = packet_walk<true, false>(M, p.x, p.y, p.z, Qf + Ea, (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A, 0u,
-                                             1u, coop ? M.coop_budget : M.heavy_budget);
+                                             1u, M.heavy_budget);
     } else {
         pb.bailed = packet_walk<false, false>(M, p.x, p.y, p.z, 0.f, 1.f, SE, A, 0u, 1u, M.heavy_budget);
         if (SE.b == SE.tieb) SE.s2 = SE.b;  // a settled exact tie is a tie
@@ -785,17 +788,18 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
     }
     if (pb.bailed) {  // wave-uniform
         uint32_t slot = 0xFFFFFFFFu;
-        if (coop) {
-            if ((threadIdx.x & 63) == 0) slot = atomicAdd(CB.count, 1u);
+        if (APPROX && (M.heavy_budget & 1u)) {
+            if ((threadIdx.x & 63) == 0) slot = atomicAdd(heavy_cnt + 1, 1u);
             slot = __builtin_amdgcn_readfirstlane(slot);
         }
-        if (slot < CB.cap) {  // the walk goes on in k_query_packet_coop, from these lists
+        if (slot < COOP_CAP) {  // the walk goes on in k_query_packet_coop, from these lists
+            const CoopDesc* D = (const CoopDesc*)(heavy_cnt + 2);
             const uint32_t lane = threadIdx.x & 63u;
-            uint32_t* st = CB.state + (size_t)slot * 448u + lane;
+            uint32_t* st = D->state + (size_t)slot * 448u + lane;
             st[0] = __float_as_uint(A.B1), st[64] = __float_as_uint(A.B2), st[128] = __float_as_uint(A.B3);
             st[192] = __float_as_uint(A.B4), st[256] = A.H1, st[320] = A.H2, st[384] = A.H3;
             if (lane == 0) {
-                CB.list[slot] = (uint32_t)(i >> 6);
+                D->list[slot] = (uint32_t)(i >> 6);
                 amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
             }
         } else {
@@ -821,11 +825,11 @@ template <int KIND, bool ROBUST>
 __global__ __launch_bounds__(64 * COOP_WAVES) SDFK_PK_SGPR void k_query_packet_coop(
     MeshDev M, const float* __restrict__ pts, const uint32_t* __restrict__ perm, int64_t n, int trunc_aabb,
     void* __restrict__ out, unsigned long long* __restrict__ amb_mask, uint32_t* __restrict__ amb_cnt, uint32_t off,
-    uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, CoopBuf CB) {
+    uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, CoopDesc CB) {
     __shared__ uint32_t sS[COOP_WAVES][7][64];
     __shared__ uint32_t s_over;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t cnt = min(*CB.count, CB.cap);
+    const uint32_t cnt = min(heavy_cnt[1], COOP_CAP);
     for (uint32_t e = blockIdx.x; e < cnt; e += gridDim.x) {  // block-uniform
         if (threadIdx.x == 0) s_over = 0u;
         __syncthreads();

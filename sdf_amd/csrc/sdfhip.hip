@@ -130,8 +130,6 @@ struct GridBuf {
 
 // Device workspace of one query call: Morton keys / permutation of the query sort (+ the sorter's
 // alternates and histograms), the per-wave masks of deferred queries, the deferred / heavy lists.
-constexpr uint32_t COOP_CAP = 16384;  // packets one launch can hand to k_query_packet_coop (28 MiB of lists)
-
 struct QueryWs {
     uint32_t* qkeys = nullptr;
     uint32_t* qperm = nullptr;
@@ -142,7 +140,7 @@ struct QueryWs {
     uint32_t* amb_s2 = nullptr;
     uint32_t* fb_list = nullptr;   // [0, cap): deferred near-tie queries; [cap, 2 cap): heavy-wave queries
     uint32_t* fb_count = nullptr;  // [0], [1] length of the deferred list (ping-pong, see k_fb_compact), [2] heavy list,
-                                   // [3] packets handed to the cooperative kernel
+                                   // [3] packets handed to the cooperative kernel, [4..7] its CoopDesc
     uint32_t* coop_list = nullptr;   // [COOP_CAP] (null in the static scratch: no cooperative kernel there)
     uint32_t* coop_state = nullptr;  // [COOP_CAP][7][64]
     int64_t q_cap = 0, fb_cap = 0;
@@ -188,7 +186,7 @@ struct sdfhip_ctx {
                                    // last call's heavy waves (read back only while profiling)
     int64_t opt_heavy_budget = 0;  // chunks per wave before it gives up; 0 = automatic
     int64_t opt_coop_budget = 1500;  // work units after which a packet goes on in the cooperative kernel; 0 = never
-    int64_t opt_coop_max = 8 << 20;  // launches of more points than this keep their long waves
+    int64_t opt_coop_max = 16 << 20;  // launches of more points than this keep their long waves
     int64_t opt_scan_max = -1;  // n x positions up to which a batch is answered by the exact scan; -1 = automatic
     int64_t opt_packet = 1;
     int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
@@ -301,7 +299,7 @@ int scratch_carve(unsigned char* base, QueryWs* W) {
     W->amb_s1 = (uint32_t*)take(4 * (nw / 2048 + 4));
     W->amb_s2 = (uint32_t*)take(4 * (nw / 2048 / 2048 + 4));
     W->qbounds = (uint32_t*)take(4 * 8);
-    W->fb_count = (uint32_t*)take(4 * 4);
+    W->fb_count = (uint32_t*)take(4 * 8);
     W->q_cap = W->fb_cap = (int64_t)n;
     W->fixed = true;
     if (off > SCRATCH_BYTES) return fail(SDFHIP_E_STATE, "static scratch too small (%zu > %zu bytes)", off, SCRATCH_BYTES);
@@ -884,6 +882,8 @@ int reserve_query_ws(sdfhip_ctx* h, int64_t n, int64_t fb_cap) {
         if (!W.coop_list) {
             if (int rc = dalloc(&W.coop_list, (size_t)COOP_CAP)) return rc;
             if (int rc = dalloc(&W.coop_state, (size_t)COOP_CAP * 448)) return rc;
+            const CoopDesc D = {W.coop_list, W.coop_state};
+            HIPC(hipMemcpy(W.fb_count + 4, &D, sizeof(D), hipMemcpyHostToDevice));
         }
         W.q_cap = n;
     }
@@ -1038,21 +1038,23 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             h->last_kernel = approx ? SDFHIP_KERNEL_PACKET_APPROX : SDFHIP_KERNEL_PACKET_EXACT;
             // Long walks go on in the cooperative kernel (8 waves per packet); not for ray-only contains().
             // It is one more serial phase (~0.4 ms): it pays while the launch is short enough for its few long
-            // waves to be the tail (nn 4M 2.68 -> 2.26 ms), not when they overlap the rest of a long launch
-            // anyway (256^3 grid in one launch: 3.67 -> 3.78 ms).
+            // waves to be the tail (nn 4M 2.68 -> 2.26 ms, 4 x 16M 13.99 -> 13.68 ms), not when they overlap the
+            // rest of a long launch anyway (256^3 grid, 16.8M points in one launch: 3.67 -> 3.78 ms).
             const bool coop = approx && M.coop_budget != 0u && W.coop_list && !(ROBUST && KIND == Q_CONTAINS) &&
                               m <= h->opt_coop_max;
-            const CoopBuf CB = {W.coop_list, W.coop_state, W.fb_count + 3, coop ? COOP_CAP : 0u};
+            MeshDev Mm = M;  // the main kernel's view: its budget, and in the low bit who takes over beyond it
+            Mm.heavy_budget = coop ? (M.coop_budget | 1u) : (M.heavy_budget & ~1u);
             if (approx)
                 k_query_packet<PK, ROBUST, true><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, 0, s>>>(
-                    M, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
-                    W.fb_list + W.fb_cap, W.fb_count + 2, CB);
+                    Mm, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
+                    W.fb_list + W.fb_cap, W.fb_count + 2);
             else
                 k_query_packet<PK, ROBUST, false><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, 0, s>>>(
-                    M, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
-                    W.fb_list + W.fb_cap, W.fb_count + 2, CB);
+                    Mm, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
+                    W.fb_list + W.fb_cap, W.fb_count + 2);
             if (coop) {
                 const int64_t npk = (m + 63) / 64;
+                const CoopDesc CB = {W.coop_list, W.coop_state};
                 k_query_packet_coop<PK, ROBUST><<<(uint32_t)(npk < 1024 ? npk : 1024), 64 * COOP_WAVES, 0, s>>>(
                     M, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
                     W.fb_list + W.fb_cap, W.fb_count + 2, CB);
@@ -1114,8 +1116,8 @@ int run_query(sdfhip_ctx* h, int kind, const float* d_pts, int64_t n, int trunc,
 // host-pointer entry: the batch is cut into chunks that flow through two device staging slots,
 //   H2D(c+1) on s_in  ||  query(c) on the handle's stream  ||  D2H(c-1) on s_out,
 // so that the PCIe transfers of pageable caller memory (blocking for the host, asynchronous
-// for the GPU) overlap the kernels.  Chunks stay large (>= n/4, up to 2^25 points): the packet
-// pass is faster on dense Morton-sorted batches.
+// for the GPU) overlap the kernels.  Chunks stay large (see the schedule in run_query_host): the
+// packet pass is faster on dense Morton-sorted batches and every chunk pays the serial phases once.
 int ensure_host_staging(sdfhip_ctx* h, int64_t cap) {
     if (!h->s_in) HIPC(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
     if (!h->s_out) HIPC(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
@@ -1149,16 +1151,29 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
     DevGuard g(h->device);
     if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
     const size_t osz = kind == Q_CONTAINS ? 1 : (kind == Q_DETAIL ? 12 : 4);
-    int64_t cap = h->opt_host_chunk;
-    if (cap <= 0) {
-        cap = (n + 3) / 4;
-        if (cap < (1 << 21)) cap = 1 << 21;
-        if (cap > (1 << 25)) cap = 1 << 25;
+    // Chunk schedule (start[c] .. start[c + 1]).  Every chunk pays ~1.6-2 ms of serial phases on the device
+    // (sort passes, the tail of the long walks, the deferred lists) next to ~0.2 ms per million points, and
+    // a page-locked upload moves a million points in ~0.22 ms: a batch of up to 8M points gains nothing from
+    // being cut; a larger one starts with a quarter of the points (the only upload nothing overlaps) and
+    // goes on in equal chunks of up to 12M (32M: 8 + 12 + 12, not 4 x 8).
+    std::vector<int64_t> start{0};
+    if (h->opt_host_chunk > 0) {
+        for (int64_t o = h->opt_host_chunk; o < n; o += h->opt_host_chunk) start.push_back(o);
+    } else if (h->robust && kind == Q_CONTAINS) {
+        // the ray walk alone has next to no serial phase: quarters (2M .. 32M points) overlap best
+        const int64_t per = std::min<int64_t>(std::max<int64_t>((n + 3) / 4, 1 << 21), 1 << 25);
+        for (int64_t o = per; o < n; o += per) start.push_back(o);
+    } else if (n > (8ll << 20)) {
+        const int64_t first = std::min<int64_t>(n / 4, 8ll << 20), rest = n - first;
+        const int64_t k = (rest + (12ll << 20) - 1) / (12ll << 20), per = (rest + k - 1) / k;
+        for (int64_t o = first; o < n; o += per) start.push_back(o);
     }
-    if (cap > n) cap = n;
+    start.push_back(n);
+    const int64_t nchunks = (int64_t)start.size() - 1;
+    int64_t cap = 0;
+    for (int64_t c = 0; c < nchunks; ++c) cap = std::max(cap, start[c + 1] - start[c]);
     if (int rc = ensure_host_staging(h, cap)) return rc;
     if (int rc = wait_for_queries(h, h->stream)) return rc;  // (this call ends synchronised: nothing to mark)
-    const int64_t nchunks = (n + cap - 1) / cap;
     if (nchunks == 1) {  // nothing to overlap: one stream, no helper thread (latency of small calls)
         hipStream_t s = h->stream;
         HIPC(hipMemcpyAsync(h->d_stage_in[0], pts, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
@@ -1170,12 +1185,12 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
         HIPC(hipStreamSynchronize(s));
         return 0;
     }
-    auto span = [&](int64_t c) { return (n - c * cap) < cap ? (n - c * cap) : cap; };
+    auto span = [&](int64_t c) { return start[c + 1] - start[c]; };
     int rc = 0;
     hipError_t e = hipSuccess;
     auto upload = [&](int64_t c) {
         const int k = (int)(c & 1);
-        e = hipMemcpyAsync(h->d_stage_in[k], pts + 3 * c * cap, sizeof(float) * 3 * (size_t)span(c),
+        e = hipMemcpyAsync(h->d_stage_in[k], pts + 3 * start[c], sizeof(float) * 3 * (size_t)span(c),
                            hipMemcpyHostToDevice, h->s_in);
         if (e == hipSuccess) e = hipEventRecord(h->ev_in[k], h->s_in);
     };
@@ -1209,7 +1224,7 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
             const int k = (int)(c & 1);
             hipError_t ed = hipStreamWaitEvent(h->s_out, h->ev_done[k], 0);
             if (ed == hipSuccess)
-                ed = hipMemcpyAsync((char*)out + osz * (size_t)(c * cap), h->d_stage_out[k],
+                ed = hipMemcpyAsync((char*)out + osz * (size_t)start[c], h->d_stage_out[k],
                                     osz * (size_t)span(c), hipMemcpyDeviceToHost, h->s_out);
             if (ed == hipSuccess) ed = hipStreamSynchronize(h->s_out);
             std::lock_guard<std::mutex> l(mx);
@@ -1389,7 +1404,7 @@ static int create_impl(const float* verts, uint32_t nv, const uint32_t* faces, u
     if (!rc) h->h_counts[0] = h->h_counts[1] = 0;
     A(dalloc(&h->d_verts, 3 * (size_t)nv));
     A(dalloc(&h->d_faces, 3 * (size_t)nf));
-    A(dalloc(&h->ws.fb_count, 4));
+    A(dalloc(&h->ws.fb_count, 8));
     A(dalloc(&h->d_adj_off, (size_t)nv + 1));
     A(dalloc(&h->d_adj_faces, 3 * (size_t)nf));
     A(dalloc(&h->d_geo, 4 * (size_t)nf));

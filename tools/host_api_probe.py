@@ -9,11 +9,14 @@ from sdf_amd import meshes
 v, f = meshes.torus(424, 424)
 s = sdf_amd.SDF(v, f); s.set_raycast_axes(meshes.random_rotation(1234))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32_000_000
+for kv in sys.argv[2:]:  # key=value handle options
+    s.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+modes = ("pinned",) if os.environ.get("PINNED_ONLY") else ("pageable", "pinned")
 pts = np.random.default_rng(7).uniform(-1, 1, (n, 3)).astype(np.float32)
 ppts = sdf_amd.pinned_empty((n, 3), np.float32); ppts[:] = pts
 outs = {"sdf": (np.float32, s.__call__), "contains": (np.bool_, s.contains), "nn": (np.int32, s.nn)}
 ref = {}
-for mode in ("pageable", "pinned"):
+for mode in modes:
     for name, (dt, fn) in outs.items():
         src = ppts if mode == "pinned" else pts
         out = sdf_amd.pinned_empty(n, dt) if mode == "pinned" else np.zeros(n, dt)
