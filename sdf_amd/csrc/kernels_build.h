@@ -143,18 +143,40 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, i
             atomicMax(&b[d], f2ord(v));
     }
 }
-__global__ void k_query_morton(const float* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ b,
-                               uint32_t* __restrict__ keys) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// One radix-sort tile per block (element (k, t) = base + k * 256 + t as in radix_sort.h): the keys, and the
+// tile's digit histogram of the first sort pass (what k_rs_hist would read the keys again for).
+__global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __restrict__ pts, uint32_t n,
+                                                             const uint32_t* __restrict__ b, uint32_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ hist, uint32_t ntiles) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
     float lo[3], inv[3];
     for (int d = 0; d < 3; ++d) {
         lo[d] = ord2f(b[d]);
         const float ext = ord2f(b[3 + d]) - lo[d];
         inv[d] = ext > 0.f ? 1024.f / ext : 0.f;
     }
-    // 8 bits per axis are plenty for wave coherence: 3 radix passes instead of 4
-    keys[i] = morton30(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], lo, inv) >> 6;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+    float x[RS_ITEMS], y[RS_ITEMS], z[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+        const size_t j = 3 * (size_t)(i < n ? i : n - 1);
+        x[k] = pts[j], y[k] = pts[j + 1], z[k] = pts[j + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+        if (i < n) {
+            // 8 bits per axis are plenty for wave coherence: 3 radix passes instead of 4
+            const uint32_t key = morton30(x[k], y[k], z[k], lo, inv) >> 6;
+            keys[i] = key;
+            atomicAdd(&h[key & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
 // =========================================================================================

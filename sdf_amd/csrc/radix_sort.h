@@ -14,27 +14,37 @@ constexpr int RS_ITEMS = 12;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 3072
 constexpr int RS_CHUNKS = RS_TILE / 64;         // 48
 
-// element (k, t) of a tile = index base + k * 256 + t, so a wave reads 64 consecutive keys
+// element (k, t) of a tile = index base + k * 256 + t, so a wave reads 64 consecutive keys.
+// A block takes RS_HT consecutive tiles: with one 12 KB tile per block the launch of 41k blocks (125M keys)
+// was what bounded the kernel (0.18 ms for 0.5 GB).
+constexpr int RS_HT = 4;
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t* __restrict__ keys, uint32_t n,
                                                         int shift, uint32_t* __restrict__ hist,
                                                         uint32_t ntiles) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * RS_TILE;
-    uint32_t key[RS_ITEMS];
+    __shared__ uint32_t h[RS_HT][256];
 #pragma unroll
-    for (int k = 0; k < RS_ITEMS; ++k) {  // all loads in flight before the first LDS atomic
-        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
-        key[k] = keys[i < n ? i : n - 1];
-    }
-#pragma unroll
-    for (int k = 0; k < RS_ITEMS; ++k) {
-        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(key[k] >> shift) & 255u], 1u);
-    }
+    for (int t = 0; t < RS_HT; ++t) h[t][threadIdx.x] = 0;
     __syncthreads();
-    hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+    const uint32_t tile0 = blockIdx.x * RS_HT;
+    uint32_t key[RS_HT][RS_ITEMS];
+#pragma unroll
+    for (int t = 0; t < RS_HT; ++t)
+#pragma unroll
+        for (int k = 0; k < RS_ITEMS; ++k) {  // all loads in flight before the first LDS atomic
+            const uint32_t i = (tile0 + t) * RS_TILE + k * RS_THREADS + threadIdx.x;
+            key[t][k] = keys[i < n ? i : n - 1];
+        }
+#pragma unroll
+    for (int t = 0; t < RS_HT; ++t)
+#pragma unroll
+        for (int k = 0; k < RS_ITEMS; ++k) {
+            const uint32_t i = (tile0 + t) * RS_TILE + k * RS_THREADS + threadIdx.x;
+            if (i < n) atomicAdd(&h[t][(key[t][k] >> shift) & 255u], 1u);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RS_HT; ++t)
+        if (tile0 + t < ntiles) hist[threadIdx.x * ntiles + tile0 + t] = h[t][threadIdx.x];
 }
 
 // block-level exclusive scan of 2048 entries per block; block totals to sums[]
@@ -103,10 +113,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     __shared__ uint32_t bstart[256];           // first local slot of each digit
     __shared__ uint32_t gbase[256];            // global base of each digit for this tile
     __shared__ uint32_t wsum[4];
+    // Blocks go round-robin over the 8 XCDs, each with its own L2.  A tile writes runs of ~12 elements
+    // (48 B) per digit, and the next tile's run follows it in memory: with XCD x taking the x-th eighth of
+    // the tiles, neighbouring runs are written through the same L2 at about the same time and leave it
+    // as whole lines.  (grid = 8 * ceil(ntiles / 8) blocks.)
+    const uint32_t tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;  // block-uniform
     for (int k = threadIdx.x; k < RS_CHUNKS * 256; k += RS_THREADS) cnt[k] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t base = blockIdx.x * RS_TILE;
+    const uint32_t base = tile * RS_TILE;
     uint32_t key[RS_ITEMS], val[RS_ITEMS];
     uint16_t rank[RS_ITEMS];
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
         uint32_t woff = 0;
         for (int k = 0; k < w; ++k) woff += wsum[k];
         bstart[dg] = woff + x - run;
-        gbase[dg] = hist[dg * ntiles + blockIdx.x];
+        gbase[dg] = hist[dg * ntiles + tile];
     }
     __syncthreads();
     for (int k = 0; k < RS_ITEMS; ++k) {  // rank[] becomes the slot in the tile
@@ -207,8 +223,9 @@ struct RadixSorter {
     // is in *keys_out / *vals_out: the caller's buffers after an even number of passes, the
     // sorter's alternates after an odd number.  iota = 1: input values are taken as 0..n-1.
     // keys_wanted = false: only the permutation is needed; the last pass then writes no keys.
+    // hist0_done: the caller's key kernel has filled `hist` for the first pass (k_query_morton does).
     int sort(uint32_t* keys, uint32_t* vals, uint32_t n, int bits, int iota, hipStream_t s,
-             uint32_t** keys_out, uint32_t** vals_out, bool keys_wanted = true) {
+             uint32_t** keys_out, uint32_t** vals_out, bool keys_wanted = true, bool hist0_done = false) {
         if (keys_out) *keys_out = keys;
         if (vals_out) *vals_out = vals;
         if (n == 0) return 0;
@@ -221,9 +238,10 @@ struct RadixSorter {
         uint32_t *ki = keys, *vi = vals, *ko = keys_alt, *vo = vals_alt;
         for (int p = 0; p < passes; ++p) {
             const int shift = 8 * p;
-            k_rs_hist<<<ntiles, RS_THREADS, 0, s>>>(ki, n, shift, hist, ntiles);
+            if (p > 0 || !hist0_done)
+                k_rs_hist<<<(ntiles + RS_HT - 1) / RS_HT, RS_THREADS, 0, s>>>(ki, n, shift, hist, ntiles);
             exclusive_scan_u32(hist, nh, sums1, sums2, s);
-            k_rs_scatter<<<ntiles, RS_THREADS, 0, s>>>(ki, vi, (p == passes - 1 && !keys_wanted) ? nullptr : ko, vo, n,
+            k_rs_scatter<<<8u * ((ntiles + 7u) / 8u), RS_THREADS, 0, s>>>(ki, vi, (p == passes - 1 && !keys_wanted) ? nullptr : ko, vo, n,
                                                        shift, hist, ntiles, (p == 0 && iota) ? 1 : 0);
             uint32_t* t = ki;
             ki = ko, ko = t;

@@ -1019,10 +1019,11 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             const int64_t groups = m / 4 / sample;
             const int nb = (int)((groups + 255) / 256 < 1024 ? (groups + 255) / 256 + 1 : 1024);
             k_bounds<<<nb, 256, 0, s>>>(p, m, W.qbounds, sample);
-            k_query_morton<<<(uint32_t)((m + 255) / 256), 256, 0, s>>>(p, (uint32_t)m, W.qbounds,
-                                                                       W.qkeys);
+            if (int rc = W.sorter.reserve((uint32_t)m)) return rc;  // (the key kernel fills its first histogram)
+            const uint32_t ntiles = (uint32_t)((m + RS_TILE - 1) / RS_TILE);
+            k_query_morton<<<ntiles, RS_THREADS, 0, s>>>(p, (uint32_t)m, W.qbounds, W.qkeys, W.sorter.hist, ntiles);
             uint32_t* sorted_perm = nullptr;
-            if (int rc = W.sorter.sort(W.qkeys, W.qperm, (uint32_t)m, 24, 1, s, nullptr, &sorted_perm, false))
+            if (int rc = W.sorter.sort(W.qkeys, W.qperm, (uint32_t)m, 24, 1, s, nullptr, &sorted_perm, false, true))
                 return rc;
             perm = sorted_perm;
         }
