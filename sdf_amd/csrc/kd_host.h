@@ -55,19 +55,6 @@ struct KdNodeH {  // 64 B
 };
 static_assert(sizeof(KdNodeH) == 64, "device layout");
 
-// Two binary levels collapsed into one 4-wide node for the packet pass (half as many dependent
-// load -> test -> branch steps per query wave).  Slots 0,1 come from binary child 1 (its two
-// children, or itself in slot 0 if it is a leaf), slots 2,3 from child 2; an unused slot has
-// an inverted infinite box, whose lower bound is +inf.  Search-order data (divlow/divhigh)
-// is not needed here: the packet pass orders children by their box distances and settles
-// ties on the binary tree.
-struct KdQuadH {  // 128 B
-    float box[4][6];  // lo xyz, hi xyz
-    uint32_t ref[4];  // quad node index, or with bit 31 a packet group: (first pos / 4) << 4 | chunks
-    uint32_t pad[4];
-};
-static_assert(sizeof(KdQuadH) == 128, "device layout");
-
 constexpr uint32_t KD_LEAF_BIT = 0x80000000u;
 constexpr uint32_t KD_FEAT_SHIFT = 29;
 constexpr uint32_t KD_REF_MASK = 0x1FFFFFFFu;  // strips leaf bit and feat bits
@@ -170,9 +157,6 @@ struct KdHost {
     int depth = 0;                    // max internal nodes on a root-to-leaf path
     float bbox[6] = {0, 0, 0, 0, 0, 0};  // min xyz, max xyz (= mesh AABB, sdf.cpp:36-37)
 
-    std::vector<KdQuadH> quads;  // 4-wide collapse of `nodes`, DFS pre-order
-    uint32_t quad_root = KD_LEAF_BIT;
-    int quad_depth = 0;
     float t_top_ms = 0, t_ranges_ms = 0, t_splice_ms = 0;  // phases of the last parallel build
 
     // threads <= 1: serial.  Otherwise up to ~2*threads ranges are built concurrently.
@@ -181,7 +165,6 @@ struct KdHost {
     // min xyz, max xyz of the points (the root box of the tree == the mesh AABB, sdf.cpp:36-37);
     // zeros for n == 0.  Data-parallel for large n.
     void bounds(const float* pts, uint32_t n, int threads, float out[6]);
-    void build_quads();
     // The packet groups in position order (= nanoflann's DFS order, spatially coherent): refs
     // KD_LEAF_BIT | (first pos / 4) << 4 | chunks.  The wide packet walk bounds each group, and
     // each run of 64 consecutive groups, by an oriented box (kernels_build.h k_group_obb).
@@ -234,13 +217,6 @@ struct KdHost {
     std::vector<int32_t> scrL_, scrR_;
     void assemble(int t, Sub& out);
     void splice(const Sub& s, uint32_t node_off, uint32_t pos_off);
-    struct QuadTask {
-        uint32_t ref, self;
-    };
-    uint32_t quad_of(uint32_t ref, int level, uint32_t self, int& max_level, int task_level,
-                     std::vector<QuadTask>* tasks);
-    std::vector<uint32_t> qsize_;  // per binary node: quad nodes of its subtree
-    uint32_t quad_size(uint32_t ref) const { return (ref & KD_LEAF_BIT) ? 0u : qsize_[ref & KD_REF_MASK]; }
     std::vector<uint32_t> sub_first_, sub_count_;  // per binary node: first position, vertices
     void subtree_extent(uint32_t ref, uint32_t& first, uint32_t& count) const {
         if (ref & KD_LEAF_BIT)
@@ -768,69 +744,6 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads, const float
     root_ref = top.c1 ? 0u : top.root;
 }
 
-// Quad nodes are numbered in DFS pre-order.  The number of quad nodes below every binary node is
-// known beforehand (qsize_), so a subtree's nodes have a fixed index range and subtrees can be
-// written concurrently: `tasks` != nullptr defers the subtrees at level `task_level`.
-inline uint32_t KdHost::quad_of(uint32_t ref, int level, uint32_t self, int& max_level, int task_level,
-                                std::vector<QuadTask>* tasks) {
-    ref &= ~(3u << KD_FEAT_SHIFT);
-    {   // a subtree of <= group_max vertices is one packet group (its block starts at a
-        // multiple of 4: the builder opened it at exactly this subtree)
-        uint32_t first, count;
-        subtree_extent(ref, first, count);
-        if (count <= group_max) return KD_LEAF_BIT | ((first >> 2) << 4) | ((count + 3u) >> 2);
-    }
-    if (tasks && level == task_level) {
-        tasks->push_back({ref, self});
-        return self;
-    }
-    if (level + 1 > max_level) max_level = level + 1;
-    const float inf = __builtin_inff();
-    KdQuadH q;
-    for (int k = 0; k < 4; ++k) {
-        for (int d = 0; d < 3; ++d) q.box[k][d] = inf, q.box[k][3 + d] = -inf;
-        // an unused slot is an EMPTY GROUP, never a quad index: its lower bound is +inf, which
-        // still passes `lb <= best * c` while best * c overflows (first descent; queries so far
-        // away that every distance is +inf), and a stale index 0 would send the walk back to the
-        // root for ever
-        q.ref[k] = KD_LEAF_BIT;
-        q.pad[k] = 0;
-    }
-    const KdNodeH nd = nodes[ref];
-    const uint32_t child[2] = {nd.ref1 & ~(3u << KD_FEAT_SHIFT), nd.ref2};
-    const float* cbox[2][2] = {{nd.lo1, nd.hi1}, {nd.lo2, nd.hi2}};
-    uint32_t gref[4] = {0, 0, 0, 0};
-    bool used[4] = {false, false, false, false};
-    for (int side = 0; side < 2; ++side) {
-        uint32_t cfirst, ccount;
-        subtree_extent(child[side], cfirst, ccount);
-        if (ccount <= group_max) {
-            const int k = 2 * side;
-            for (int d = 0; d < 3; ++d) q.box[k][d] = cbox[side][0][d], q.box[k][3 + d] = cbox[side][1][d];
-            gref[k] = child[side];
-            used[k] = true;
-        } else {
-            const KdNodeH c = nodes[child[side]];
-            const int k = 2 * side;
-            for (int d = 0; d < 3; ++d) {
-                q.box[k][d] = c.lo1[d], q.box[k][3 + d] = c.hi1[d];
-                q.box[k + 1][d] = c.lo2[d], q.box[k + 1][3 + d] = c.hi2[d];
-            }
-            gref[k] = c.ref1 & ~(3u << KD_FEAT_SHIFT);
-            gref[k + 1] = c.ref2;
-            used[k] = used[k + 1] = true;
-        }
-    }
-    uint32_t next = self + 1;  // pre-order: the children's subtrees follow, slot by slot
-    for (int k = 0; k < 4; ++k)
-        if (used[k]) {
-            q.ref[k] = quad_of(gref[k], level + 1, next, max_level, task_level, tasks);
-            next += quad_size(gref[k]);
-        }
-    quads[self] = q;
-    return self;
-}
-
 inline void KdHost::build_groups() {
     groups.clear();
     if (pos_vert.empty()) return;
@@ -857,51 +770,6 @@ inline void KdHost::build_groups() {
         }
         stack.push_back(nodes[ref].ref2);
         stack.push_back(nodes[ref].ref1 & ~(3u << KD_FEAT_SHIFT));
-    }
-}
-
-inline void KdHost::build_quads() {
-    // extents of every binary subtree and the number of quad nodes below it (children follow
-    // their parent in pre-order, so one reverse pass does)
-    sub_first_.assign(nodes.size(), 0u);
-    sub_count_.assign(nodes.size(), 0u);
-    qsize_.assign(nodes.size(), 0u);
-    for (size_t i = nodes.size(); i-- > 0;) {
-        uint32_t f1, c1, f2, c2;
-        const uint32_t r1 = nodes[i].ref1 & ~(3u << KD_FEAT_SHIFT), r2 = nodes[i].ref2;
-        subtree_extent(r1, f1, c1);
-        subtree_extent(r2, f2, c2);
-        sub_first_[i] = f1;
-        sub_count_[i] = c1 + c2;
-        if (c1 + c2 <= group_max) continue;  // a group: no quad node
-        uint32_t q = 1;
-        const uint32_t rs[2] = {r1, r2}, cs[2] = {c1, c2};
-        for (int side = 0; side < 2; ++side)
-            if (cs[side] > group_max) {  // (then an internal node) its two children become slots
-                const KdNodeH& c = nodes[rs[side]];
-                q += quad_size(c.ref1 & ~(3u << KD_FEAT_SHIFT)) + quad_size(c.ref2);
-            }
-        qsize_[i] = q;
-    }
-    quad_depth = 0;
-    const uint32_t total = quad_size(root_ref);
-    quads.assign(total, KdQuadH{});
-    if (team_ && total >= 2048) {
-        std::vector<QuadTask> tasks;
-        int top_level = 0;
-        quad_root = quad_of(root_ref, 0, 0, top_level, 3, &tasks);
-        std::vector<int> lv(tasks.size(), 0);
-        team_->begin();
-        team_->run((int)tasks.size(), [&](int t) {
-            int ml = 0;
-            quad_of(tasks[t].ref, 3, tasks[t].self, ml, -1, nullptr);
-            lv[t] = ml;
-        });
-        team_->end();
-        quad_depth = top_level;
-        for (int v : lv) quad_depth = v > quad_depth ? v : quad_depth;
-    } else {
-        quad_root = quad_of(root_ref, 0, 0, quad_depth, -1, nullptr);
     }
 }
 

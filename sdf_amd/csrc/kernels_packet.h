@@ -39,9 +39,6 @@
 #ifndef SDFK_CHUNK_BATCH
 #define SDFK_CHUNK_BATCH 3
 #endif
-#ifndef SDFK_EXP
-#define SDFK_EXP 0
-#endif
 #ifndef SDFK_PBLOCK
 #define SDFK_PBLOCK 64
 #endif
@@ -399,9 +396,6 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
     const uint32_t lane = threadIdx.x & 63u;
     SDFK_COUNT(0, 1);
     if (M.kd_ngroups == 0u) return false;
-#if SDFK_EXP == 3
-    return false;
-#endif
     // sphere around the wave's queries: centre of their bounding box, radius = farthest query
     const float cx = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(qx))) + pk_ord2f(wave_umax(pk_f2ord(qx))));
     const float cy = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(qy))) + pk_ord2f(wave_umax(pk_f2ord(qy))));
@@ -472,9 +466,6 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
         gx = wave_readf(o.nx, g0), gy = wave_readf(o.ny, g0), gz = wave_readf(o.nz, g0);
         if (!(fabsf(gx) <= 1.f && fabsf(gy) <= 1.f && fabsf(gz) <= 1.f)) gx = gy = gz = 0.f;
     }
-#if SDFK_EXP == 1
-    return false;
-#endif
     // ---- the walk: L1 rows -> candidate L1 nodes -> candidate groups -> plane test -> evaluation
     // packet-level threshold: max over the lanes of rr_l - g.e_l (+ slack of the dot product)
 #define SDFK_PK_RES() \

@@ -1,5 +1,6 @@
 // The task-parallel kd build must produce byte-identical arrays to the serial build, and the
-// packet groups of the 4-wide tree must tile the padded position space exactly.
+// packet groups (maximal subtrees of <= group_max vertices, in position order) must tile the padded
+// position space exactly.
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -15,25 +16,17 @@ static bool groups_ok(const sdfk::KdHost& k, int n) {
         for (uint32_t i = first; i < first + 4 * chunks; ++i) seen[i]++;
         return true;
     };
-    if (k.quad_root & sdfk::KD_LEAF_BIT) {
-        if (!mark(k.quad_root)) return false;
+    uint32_t next = 0;  // groups are listed in position order and tile the padded positions
+    for (uint32_t ref : k.groups) {
+        if (!(ref & sdfk::KD_LEAF_BIT) || !mark(ref)) return false;
+        const uint32_t first = ((ref & sdfk::KD_REF_MASK) >> 4) << 2, chunks = ref & 15u;
+        if (first != next) return false;
+        next = first + 4 * chunks;
+        int real = 0;
+        for (uint32_t i = first; i < first + 4 * chunks; ++i) real += k.pos_vert[i] >= 0;
+        // (an empty leaf, which nanoflann can produce on degenerate splits, is no group at all)
+        if (real == 0 || real > (int)k.group_max) return false;
     }
-    for (const auto& q : k.quads)
-        for (int s = 0; s < 4; ++s) {
-            const bool used = q.box[s][0] <= q.box[s][3];
-            if (!used) continue;
-            if (q.ref[s] & sdfk::KD_LEAF_BIT) {
-                if (!mark(q.ref[s])) return false;
-                // every vertex of the group lies in the slot's box
-                const uint32_t first = ((q.ref[s] & sdfk::KD_REF_MASK) >> 4) << 2, chunks = q.ref[s] & 15u;
-                int real = 0;
-                for (uint32_t i = first; i < first + 4 * chunks; ++i) real += k.pos_vert[i] >= 0;
-                // (an empty leaf, which nanoflann can produce on degenerate splits, is an empty group)
-                if ((real == 0) != (chunks == 0) || real > (int)k.group_max) return false;
-            } else if (q.ref[s] >= k.quads.size()) {
-                return false;
-            }
-        }
     for (size_t i = 0; i < seen.size(); ++i)
         if (seen[i] != 1) return false;
     for (int32_t v : k.pos_vert)
@@ -68,14 +61,12 @@ int main() {
                 a.build(p.data(), n, 1);
                 b.build(p.data(), n, g == 16u ? 3 : (g == 32u ? 16 : 8));
                 b.build(p.data(), n, g == 16u ? 3 : (g == 32u ? 16 : 8));  // (a rebuild reuses the team)
-                a.build_quads();
-                b.build_quads();
+                a.build_groups();
+                b.build_groups();
                 bool ok = a.root_ref == b.root_ref && a.depth == b.depth && a.vind == b.vind &&
                           a.pos_vert == b.pos_vert && a.split == b.split && a.nodes.size() == b.nodes.size() &&
                           !memcmp(a.nodes.data(), b.nodes.data(), a.nodes.size() * sizeof(sdfk::KdNodeH)) &&
-                          !memcmp(a.bbox, b.bbox, sizeof(a.bbox)) && a.quad_root == b.quad_root && a.quad_depth == b.quad_depth &&
-                          a.quads.size() == b.quads.size() &&
-                          !memcmp(a.quads.data(), b.quads.data(), a.quads.size() * sizeof(sdfk::KdQuadH));
+                          !memcmp(a.bbox, b.bbox, sizeof(a.bbox)) && a.groups == b.groups;
                 if (!ok) { printf("MISMATCH n=%d mode=%d g=%u\n", n, mode, g); return 1; }
                 if (!groups_ok(a, n)) { printf("BAD GROUPS n=%d mode=%d g=%u\n", n, mode, g); return 1; }
             }

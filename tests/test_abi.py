@@ -100,3 +100,23 @@ def test_parallel_kd_build_is_identical_to_serial(tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "kd_build_check.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_packet_kernel_keeps_seven_waves_per_simd(tmp_path):
+    """The dominant kernel runs 7 waves per SIMD only with <= 72 VGPRs and <= 96 SGPRs and no scratch
+    ("registers"): two more VGPRs cost 4 % of the step.  Read from the compiler's own metadata."""
+    import subprocess
+    asm = str(tmp_path / "sdfhip.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
+                           "-fno-slp-vectorize", "-Wno-unused-result", "--cuda-device-only", "-S", "-o", asm,
+                           os.path.join(ROOT, "sdf_amd", "csrc", "sdfhip.hip")])
+    text = open(asm).read()
+    seen = 0
+    for m in re.finditer(r"\.name:\s+(_Z14k_query_packetILi([02])ELb([01])ELb1EE\S*)\n(.*?)\.wavefront_size", text, re.S):
+        body = m.group(4)
+        vg = int(re.search(r"\.vgpr_count:\s+(\d+)", body).group(1))
+        sg = int(re.search(r"\.sgpr_count:\s+(\d+)", body).group(1))
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
+        assert vg <= 72 and sg <= 96 and scratch == 0, (m.group(1), vg, sg, scratch)
+        seen += 1
+    assert seen == 4  # nn / sdf x robust / non-robust, approximate walk

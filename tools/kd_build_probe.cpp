@@ -30,8 +30,8 @@ int main(int argc, char** argv) {
     }
     {
         auto t1 = std::chrono::steady_clock::now();
-        a.build_quads();
-        std::printf("serial            %7.2f ms   quads %.2f ms\n", best, ms(t1, std::chrono::steady_clock::now()));
+        a.build_groups();
+        std::printf("serial            %7.2f ms   groups %.2f ms\n", best, ms(t1, std::chrono::steady_clock::now()));
     }
     for (int k = 1; k < argc; ++k) {
         const int th = std::atoi(argv[k]);
@@ -43,13 +43,13 @@ int main(int argc, char** argv) {
             b.build(p.data(), n, th);
             best = std::min(best, ms(t0, std::chrono::steady_clock::now()));
             auto t1 = std::chrono::steady_clock::now();
-            b.build_quads();
+            b.build_groups();
             bestq = std::min(bestq, ms(t1, std::chrono::steady_clock::now()));
         }
         const bool same = a.vind == b.vind && a.pos_vert == b.pos_vert && a.split == b.split &&
                           a.nodes.size() == b.nodes.size() &&
                           !std::memcmp(a.nodes.data(), b.nodes.data(), a.nodes.size() * sizeof(sdfk::KdNodeH));
-        std::printf("threads %2d        %7.2f ms   %s   (last: top %.2f ranges %.2f splice %.2f)  quads %.2f ms\n", th, best,
+        std::printf("threads %2d        %7.2f ms   %s   (last: top %.2f ranges %.2f splice %.2f)  groups %.2f ms\n", th, best,
                     same ? "identical" : "MISMATCH", b.t_top_ms, b.t_ranges_ms, b.t_splice_ms, bestq);
     }
     return 0;
