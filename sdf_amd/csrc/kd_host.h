@@ -37,6 +37,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -101,19 +102,37 @@ class KdTeam {
         }
         fn_ = &fn;
         nb_ = nb;
+        err_ = nullptr;
         next_.store(0, std::memory_order_relaxed);
         done_.store(0, std::memory_order_relaxed);
         spin_.fetch_add(1, std::memory_order_release);  // publish the job
         work();
         while (done_.load(std::memory_order_acquire) != (int)th_.size()) std::this_thread::yield();
+        // an exception in fn (std::bad_alloc in a range build) ends the job early and surfaces here, on
+        // the caller's thread, once every worker has left the job
+        if (err_) std::rethrow_exception(err_);
     }
+    // begin() now, end() when the scope is left (also by an exception: the workers must not keep spinning)
+    struct Session {
+        explicit Session(KdTeam& t) : t_(t) { t_.begin(); }
+        ~Session() { t_.end(); }
+        Session(const Session&) = delete;
+        Session& operator=(const Session&) = delete;
+        KdTeam& t_;
+    };
 
    private:
     void work() {
         for (;;) {
             const int b = next_.fetch_add(1, std::memory_order_relaxed);
             if (b >= nb_) break;
-            (*fn_)(b);
+            try {
+                (*fn_)(b);
+            } catch (...) {
+                std::lock_guard<std::mutex> l(m_);
+                if (!err_) err_ = std::current_exception();
+                next_.store(nb_, std::memory_order_relaxed);  // nobody starts another block
+            }
         }
     }
     void loop() {
@@ -144,6 +163,7 @@ class KdTeam {
     std::atomic<unsigned> spin_{0}, sleep_gen_{0xFFFFFFFFu};
     std::atomic<int> next_{0}, done_{0};
     const std::function<void(int)>* fn_ = nullptr;
+    std::exception_ptr err_;  // first exception of the running job (guarded by m_)
     int nb_ = 0;
 };
 
@@ -616,9 +636,8 @@ inline void KdHost::bounds(const float* pts, uint32_t n, int threads, float out[
         one(0);
     } else {
         if (!team_ || team_->size() != threads) team_.reset(new KdTeam(threads - 1));
-        team_->begin();
+        KdTeam::Session awake(*team_);
         team_->run((int)nb, one);
-        team_->end();
     }
     for (int d = 0; d < 6; ++d) out[d] = part[d];
     for (uint32_t b = 1; b < nb; ++b)
@@ -655,7 +674,9 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads, const float
         const int32_t cutoff = (int32_t)(n / 256 + 1024);
         if (!team_ || team_->size() != threads) team_.reset(new KdTeam(threads - 1));
         const auto tp0 = std::chrono::steady_clock::now();
-        team_->begin();
+        auto tp1 = tp0;
+        {   // the team stays awake for the top levels and the ranges
+        KdTeam::Session awake(*team_);
         top_.clear();
         top_.emplace_back();
         top_[0].left = 0, top_[0].right = (int32_t)n, top_[0].box = box;
@@ -689,7 +710,7 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads, const float
                 top_[t].c1 = (int)top_.size() - 2, top_[t].c2 = (int)top_.size() - 1;
             }
         }
-        const auto tp1 = std::chrono::steady_clock::now();
+        tp1 = std::chrono::steady_clock::now();
         // the ranges below the top are independent (disjoint parts of vind): largest first
         std::sort(ranges.begin(), ranges.end(), [&](int x, int y) {
             return top_[x].right - top_[x].left > top_[y].right - top_[y].left;
@@ -702,7 +723,7 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads, const float
             T.sub.pos_vert.reserve(cnt + cnt / 4 + 64);
             T.sub.root = divide(T.sub, T.left, T.right, T.box, 0, false);
         });
-        team_->end();
+        }
         const auto tp2 = std::chrono::steady_clock::now();
         t_top_ms = std::chrono::duration<float, std::milli>(tp1 - tp0).count();
         t_ranges_ms = std::chrono::duration<float, std::milli>(tp2 - tp1).count();
@@ -733,9 +754,8 @@ inline void KdHost::build(const float* pts, uint32_t n, int threads, const float
         for (size_t i = 0; i < r.pos_vert.size(); ++i) pos_vert[(size_t)J.pos_off + i] = r.pos_vert[i];
     };
     if (team_ && splice_jobs_.size() > 1) {
-        team_->begin();
+        KdTeam::Session awake(*team_);
         team_->run((int)splice_jobs_.size(), copy_range);
-        team_->end();
     } else {
         for (size_t j = 0; j < splice_jobs_.size(); ++j) copy_range((int)j);
     }
