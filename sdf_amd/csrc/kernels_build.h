@@ -591,7 +591,8 @@ __global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridPa
                              uint32_t* __restrict__ items, uint32_t* __restrict__ big,
                              uint32_t* __restrict__ nbig, int skip_nan,
                              const float4* __restrict__ rface /* a' b' c' n' per face, or nullptr: boxes only */,
-                             float4* __restrict__ ibox /* FILL: the face's x, y box beside its id, or nullptr */) {
+                             const float4* __restrict__ ent_src /* FILL: a' b' c' n' per face for the entries */,
+                             float4* __restrict__ ent /* FILL: two float4 per entry (see MeshDev::gr_ent), or nullptr */) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nf) return;
     const float* b = fbox + 6 * (size_t)f;
@@ -624,7 +625,11 @@ __global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridPa
             if (FILL) {
                 const uint32_t slot = atomicAdd(&cells[c], 1u);
                 items[slot] = f;
-                if (ibox) ibox[slot] = make_float4(b[0], b[1], b[3], b[4]);
+                if (ent) {  // the triangle in x', y' and the face id: what a ray needs before any per-face fetch
+                    const float4 f0 = ent_src[3 * (size_t)f], f1 = ent_src[3 * (size_t)f + 1];
+                    ent[2 * (size_t)slot] = make_float4(f0.x, f0.y, f0.w, f1.x);
+                    ent[2 * (size_t)slot + 1] = make_float4(f1.z, f1.w, __uint_as_float(f), 0.f);
+                }
             } else {
                 atomicAdd(&cells[c], 1u);
             }

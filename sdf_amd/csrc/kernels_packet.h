@@ -91,11 +91,6 @@ __device__ __forceinline__ int kd_dfs_first(const MeshDev& M, float qx, float qy
     return pa < pb ? pa : pb;
 }
 
-__device__ __forceinline__ float fmin3(float a, float b, float c) {
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));

@@ -46,7 +46,7 @@ struct MeshDev {
     const float* fbox;          // per face: rotated AABB min xyz, max xyz
     const uint32_t* gr_start;   // [g*g + 1]
     const uint32_t* gr_items;   // face ids, cell by cell
-    const float4* gr_ibox;      // per entry of gr_items: the face's rotated AABB in x', y' {mnx, mny, mxx, mxy}
+    const float4* gr_ent;       // per entry of gr_items, 32 B: {a'.x, a'.y, b'.x, b'.y}, {c'.x, c'.y, face id, 0}
     const uint32_t* gr_big;     // faces spanning too many cells: tested by every query
     uint32_t gr_nbig;
     int ray_lbvh;  // packet kernel: walk the LBVH cooperatively instead of the grid (long lists)
@@ -292,10 +292,12 @@ __device__ __forceinline__ void ray_face_z(const MeshDev& M, V3 q, uint32_t face
         }
     }
 }
-// The part of ray_face_z after Overlap in x and y: the z side of Overlap, facing rule, bary2d.  The z range
-// of the face's box is recomputed from its rotated corners exactly as k_face_precompute stored it.
-__device__ __forceinline__ void ray_face_z_rest(V3 q, const float4 f0, const float4 f1, const float4 f2, int& zp,
+// What is left of ray_face_z for a face whose Overlap in x, y and bary2d hold: the z side of Overlap and the
+// facing rule decide which of the two rays (if any) it counts for.  The z range of the face's box is
+// recomputed from its rotated corners exactly as k_face_precompute stored it.
+__device__ __forceinline__ void ray_face_z_side(V3 q, const float4 f0, const float4 f1, const float4 f2, int& zp,
                                                 int& zm) {
+    SDFK_RCOUNT(3);
     const float mnz = sdfk::stdmin(sdfk::stdmin(f0.z, f1.y), f2.x), mxz = sdfk::stdmax(sdfk::stdmax(f0.z, f1.y), f2.x);
     const bool okp = !(q.z > mxz || mnz > FLT_MAX);   // box [q.z, FLT_MAX]
     const bool okm = !(-FLT_MAX > mxz || mnz > q.z);  // box [-FLT_MAX, q.z]
@@ -304,17 +306,38 @@ __device__ __forceinline__ void ray_face_z_rest(V3 q, const float4 f0, const flo
     const float s = sdfk::dot(nr, dv) * nr.z;  // sdf.cpp:301-302, ax_idx = 2
     const bool pos = s > 0.f;                  // z- needs pos, z+ needs !pos
     if (pos ? okm : okp) {
-        SDFK_RCOUNT(3);
-        if (sdfk::bary2d_inside(q.x, q.y, f0.x, f0.y, f0.w, f1.x, f1.z, f1.w)) {
-            if (pos)
-                zm ^= 1;
-            else
-                zp ^= 1;
-        }
+        if (pos)
+            zm ^= 1;
+        else
+            zp ^= 1;
     }
 }
-// The cell's list carries each face's x', y' box next to its id (cell-major, read as a stream): only faces
-// that pass Overlap in x and y (a third to two thirds of the list) fetch their 48-byte record.  Two entries
+// (a NaN operand is dropped, as by fminf / fmaxf)
+__device__ __forceinline__ float fmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float fmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// Overlap in x', y' and bary2d of one list entry (the face's corners in x', y').  The box is rebuilt from the
+// corners with v_min3 / v_max3: equal to the std::min / std::max chain of k_face_precompute for corners
+// without a NaN (up to the sign of a zero, which no comparison sees); with a NaN corner the two may differ,
+// and then bary2d is false (its denominator is NaN), which is all that a failed Overlap would have meant.
+__device__ __forceinline__ bool ray_entry_inside(V3 q, const float4 e0, const float4 e1) {
+    const float mnx = fmin3(e0.x, e0.z, e1.x), mxx = fmax3(e0.x, e0.z, e1.x);
+    const float mny = fmin3(e0.y, e0.w, e1.y), mxy = fmax3(e0.y, e0.w, e1.y);
+    if ((q.x > mxx || mnx > q.x) || (q.y > mxy || mny > q.y)) return false;  // Overlap, x and y
+    SDFK_RCOUNT(2);
+    return sdfk::bary2d_inside(q.x, q.y, e0.x, e0.y, e0.z, e0.w, e1.x, e1.y);
+}
+// The cell's list carries each face's corners in x', y' next to its id (cell-major, read as a stream, 32 B per
+// entry): Overlap in x, y and bary2d need nothing else, and only the faces the column really pierces (2-6 of
+// the 50-70 listed on a rough surface) fetch their 48-byte record for the z side of Overlap and the facing
+// rule.  The order of the tests is free: a face counts iff all of them hold (sdf.cpp:296-312).  Two entries
 // per step, their loads in flight together.
 __device__ __forceinline__ void ray_z_pair_grid(const MeshDev& M, V3 q, int& zp, int& zm) {
     zp = 0;
@@ -325,23 +348,18 @@ __device__ __forceinline__ void ray_z_pair_grid(const MeshDev& M, V3 q, int& zp,
     const uint32_t e = M.gr_start[c + 1];
     for (uint32_t k = M.gr_start[c]; k < e; k += 2u) {
         const uint32_t k1 = k + 1u < e ? k + 1u : k;
-        const float4 b0 = M.gr_ibox[k], b1 = M.gr_ibox[k1];
-        const uint32_t i0 = M.gr_items[k], i1 = M.gr_items[k1];
-        const bool in0 = !((q.x > b0.z || b0.x > q.x) || (q.y > b0.w || b0.y > q.y));
-        const bool in1 = k1 != k && !((q.x > b1.z || b1.x > q.x) || (q.y > b1.w || b1.y > q.y));
+        const float4 a0 = M.gr_ent[2 * (size_t)k], a1 = M.gr_ent[2 * (size_t)k + 1];
+        const float4 b0 = M.gr_ent[2 * (size_t)k1], b1 = M.gr_ent[2 * (size_t)k1 + 1];
         SDFK_RCOUNT(1);
         if (k1 != k) SDFK_RCOUNT(1);
+        const bool in0 = ray_entry_inside(q, a0, a1);
+        const bool in1 = k1 != k && ray_entry_inside(q, b0, b1);
+        const uint32_t i0 = __float_as_uint(a1.z), i1 = __float_as_uint(b1.z);
         float4 f00, f01, f02, f10, f11, f12;
         if (in0) f00 = M.rface[3 * (size_t)i0], f01 = M.rface[3 * (size_t)i0 + 1], f02 = M.rface[3 * (size_t)i0 + 2];
         if (in1) f10 = M.rface[3 * (size_t)i1], f11 = M.rface[3 * (size_t)i1 + 1], f12 = M.rface[3 * (size_t)i1 + 2];
-        if (in0) {
-            SDFK_RCOUNT(2);
-            ray_face_z_rest(q, f00, f01, f02, zp, zm);
-        }
-        if (in1) {
-            SDFK_RCOUNT(2);
-            ray_face_z_rest(q, f10, f11, f12, zp, zm);
-        }
+        if (in0) ray_face_z_side(q, f00, f01, f02, zp, zm);
+        if (in1) ray_face_z_side(q, f10, f11, f12, zp, zm);
     }
     for (uint32_t k = 0; k < M.gr_nbig; ++k) ray_face_z(M, q, M.gr_big[k], zp, zm);
 }

@@ -108,8 +108,8 @@ struct GridBuf {
     uint32_t* start = nullptr;   // [g*g + 1]
     uint32_t* cursor = nullptr;
     uint32_t* items = nullptr;
-    float4* ibox = nullptr;      // per entry of items: the face's box in x, y (only when want_ibox)
-    bool want_ibox = false;
+    float4* ent = nullptr;       // per entry of items: the face's corners in x, y + its id, 32 B (only when want_ent)
+    bool want_ent = false;
     uint32_t* big = nullptr;
     uint32_t* nbig_dev = nullptr;
     uint32_t* s1 = nullptr;
@@ -119,11 +119,11 @@ struct GridBuf {
     bool coarsened = false;  // faces are large against the cells at the natural resolution
     GridParams gr = {1, 0.f, 0.f, 0.f, 0.f};
     void release() {
-        void* ps[] = {start, cursor, items, ibox, big, nbig_dev, s1, s2};
+        void* ps[] = {start, cursor, items, ent, big, nbig_dev, s1, s2};
         for (void* p : ps)
             if (p) (void)hipFree(p);
         start = cursor = items = big = nbig_dev = s1 = s2 = nullptr;
-        ibox = nullptr;
+        ent = nullptr;
         cells_cap = items_cap = big_cap = 0;
     }
 };
@@ -368,7 +368,8 @@ void draw_rotation(sdfhip_ctx* h) {
 // x / y range is [lo, hi]: count -> scan -> fill, three small launches (+ one retry per halving
 // when the faces are large against the cells).
 int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], const float hi[2],
-               int skip_nan, hipStream_t s, const float4* d_rface = nullptr, int64_t max_per_face = 16) {
+               int skip_nan, hipStream_t s, const float4* d_rface = nullptr, int64_t max_per_face = 16,
+               const float4* d_ent_src = nullptr /* the rotated faces, when B.want_ent */) {
     if (n == 0) {  // no faces: one empty cell (the query kernels always look their cell up)
         if (B.cells_cap < 2) {
             if (int rc = dalloc(&B.start, 2)) return rc;
@@ -407,7 +408,7 @@ int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], c
         HIPC(hipMemsetAsync(B.start, 0, sizeof(uint32_t) * cells, s));
         HIPC(hipMemsetAsync(B.nbig_dev, 0, sizeof(uint32_t), s));
         k_grid_faces<false><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.start, nullptr, B.big,
-                                                            B.nbig_dev, skip_nan, d_rface, nullptr);
+                                                            B.nbig_dev, skip_nan, d_rface, nullptr, nullptr);
         exclusive_scan_u32(B.start, (uint32_t)cells, B.s1, B.s2, s);
         uint32_t total = 0, nbig = 0;
         HIPC(hipMemcpyAsync(&total, B.start + (cells - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -422,13 +423,13 @@ int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], c
         if ((size_t)total + 1 > B.items_cap) {
             const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
             if (int rc = dalloc(&B.items, cap)) return rc;
-            if (B.want_ibox)
-                if (int rc = dalloc(&B.ibox, cap)) return rc;
+            if (B.want_ent)
+                if (int rc = dalloc(&B.ent, 2 * cap)) return rc;
             B.items_cap = cap;
         }
         HIPC(hipMemcpyAsync(B.cursor, B.start, sizeof(uint32_t) * cells, hipMemcpyDeviceToDevice, s));
         k_grid_faces<true><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.cursor, B.items, B.big,
-                                                           B.nbig_dev, skip_nan, d_rface, B.want_ibox ? B.ibox : nullptr);
+                                                           B.nbig_dev, skip_nan, d_rface, d_ent_src, B.want_ent ? B.ent : nullptr);
         HIPC(hipGetLastError());
         B.gr = G;
         B.coarsened = long_lists;
@@ -507,8 +508,8 @@ int build_grid(sdfhip_ctx* h) {
             hi[d] = r > hi[d] ? r : hi[d];
         }
     }
-    h->grid.want_ibox = true;
-    return grid_build(h->grid, h->d_fbox, h->nf, lo, hi, 0, h->stream, h->opt_grid_tri ? h->d_rface : nullptr, h->opt_grid_per_face);
+    h->grid.want_ent = true;
+    return grid_build(h->grid, h->d_fbox, h->nf, lo, hi, 0, h->stream, h->opt_grid_tri ? h->d_rface : nullptr, h->opt_grid_per_face, h->d_rface);
 }
 
 // rotation-dependent + vertex-dependent precompute; verts must already be in d_verts
@@ -790,7 +791,7 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.fbox = h->d_fbox;
     M.gr_start = h->grid.start;
     M.gr_items = h->grid.items;
-    M.gr_ibox = h->grid.ibox;
+    M.gr_ent = h->grid.ent;
     M.gr_big = h->grid.big;
     M.gr_nbig = h->robust ? h->grid.nbig : 0;
     M.gr_g = h->grid.gr.g;

@@ -23,4 +23,4 @@ s.contains(pts); torch.cuda.synchronize()
 s._L.sdfhip_debug_ray_stats(st, 1)
 q = max(1, st[0])
 print(f"{a.mesh} noise {a.noise} faces {f.shape[0]}: queries in box {st[0]} ({st[0]/a.n:.2f} of all); per such query: "
-      f"faces tested {st[1]/q:.1f}  pass Overlap xy {st[2]/q:.1f}  bary2d evaluated {st[3]/q:.1f}")
+      f"faces tested {st[1]/q:.1f}  pass Overlap xy (bary2d evaluated) {st[2]/q:.1f}  inside the triangle (record fetched) {st[3]/q:.1f}")
