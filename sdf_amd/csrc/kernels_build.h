@@ -143,19 +143,29 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, i
             atomicMax(&b[d], f2ord(v));
     }
 }
+// Sort key of robust contains(): the query's column of the ray-cast frame, a 12 + 12 bit Morton code of
+// (x', y') over the column grid's range.  The z+ / z- rays of a query read the face list of its column, so
+// the queries of one wave then share a handful of lists instead of reading 64 (the lists of a rough mesh
+// are 2 KB each: the 3-D order moved 6 TB/s for them).  r0, r1: rows of R giving x', y'.
+struct ColumnKey {
+    int on;
+    float r0[3], r1[3];
+    float o0, o1, s0, s1;  // x' -> (x' - o0) * s0 in [0, 4096)
+};
 // One radix-sort tile per block (element (k, t) = base + k * 256 + t as in radix_sort.h): the keys, and the
 // tile's digit histogram of the first sort pass (what k_rs_hist would read the keys again for).
 __global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __restrict__ pts, uint32_t n,
                                                              const uint32_t* __restrict__ b, uint32_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ hist, uint32_t ntiles) {
+                                                             uint32_t* __restrict__ hist, uint32_t ntiles, ColumnKey CK) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
-    float lo[3], inv[3];
-    for (int d = 0; d < 3; ++d) {
-        lo[d] = ord2f(b[d]);
-        const float ext = ord2f(b[3 + d]) - lo[d];
-        inv[d] = ext > 0.f ? 1024.f / ext : 0.f;
-    }
+    float lo[3] = {0.f, 0.f, 0.f}, inv[3] = {0.f, 0.f, 0.f};
+    if (!CK.on)
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = ord2f(b[d]);
+            const float ext = ord2f(b[3 + d]) - lo[d];
+            inv[d] = ext > 0.f ? 1024.f / ext : 0.f;
+        }
     __syncthreads();
     const uint32_t base = blockIdx.x * RS_TILE;
     float x[RS_ITEMS], y[RS_ITEMS], z[RS_ITEMS];
@@ -170,7 +180,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __rest
         const uint32_t i = base + k * RS_THREADS + threadIdx.x;
         if (i < n) {
             // 8 bits per axis are plenty for wave coherence: 3 radix passes instead of 4
-            const uint32_t key = morton30(x[k], y[k], z[k], lo, inv) >> 6;
+            uint32_t key;
+            if (CK.on) {
+                const float xr = __builtin_fmaf(CK.r0[0], x[k], __builtin_fmaf(CK.r0[1], y[k], CK.r0[2] * z[k]));
+                const float yr = __builtin_fmaf(CK.r1[0], x[k], __builtin_fmaf(CK.r1[1], y[k], CK.r1[2] * z[k]));
+                const float fx = fminf(fmaxf((xr - CK.o0) * CK.s0, 0.f), 4095.f);  // (NaN -> 0)
+                const float fy = fminf(fmaxf((yr - CK.o1) * CK.s1, 0.f), 4095.f);
+                key = expand16((uint32_t)fx) | (expand16((uint32_t)fy) << 1);
+            } else {
+                key = morton30(x[k], y[k], z[k], lo, inv) >> 6;
+            }
             keys[i] = key;
             atomicAdd(&h[key & 255u], 1u);
         }
@@ -545,16 +564,17 @@ struct TriCell {
     double m;                     // dilation
     bool on;
 };
-__device__ __forceinline__ TriCell tri_cell_setup(const float* bx, const float4 f0, const float4 f1, double slack) {
+// cr: the corners in the grid's two axes {a0, a1, b0, b1, c0, c1}; bw, bh: extent of the face's box in them
+__device__ __forceinline__ TriCell tri_cell_setup(double bw, double bh, const float cr[6], double slack) {
     TriCell T;
     T.on = false;
     T.m = 0;
-    const double ax = f0.x, ay = f0.y, bxx = f0.w, by = f1.x, cx = f1.z, cy = f1.w;
+    const double ax = cr[0], ay = cr[1], bxx = cr[2], by = cr[3], cx = cr[4], cy = cr[5];
     const double v0x = bxx - ax, v0y = by - ay, v1x = cx - ax, v1y = cy - ay;
     const double den = v0x * v1y - v1x * v0y;
     const double l0 = sqrt(v0x * v0x + v0y * v0y), l1 = sqrt(v1x * v1x + v1y * v1y);
     const double ex = cx - bxx, ey = cy - by, lbc = sqrt(ex * ex + ey * ey);
-    const double D = sqrt(((double)bx[3] - bx[0]) * ((double)bx[3] - bx[0]) + ((double)bx[4] - bx[1]) * ((double)bx[4] - bx[1]));
+    const double D = sqrt(bw * bw + bh * bh);
     const double aden = fabs(den);
     if (!(aden > 1e-30 && aden < 1e30 && l0 > 0 && l1 > 0 && lbc > 0 && D < 1e15)) return T;
     const double kappa = l0 * l1 / aden;
@@ -585,7 +605,18 @@ __device__ __forceinline__ bool tri_cell_excluded(const TriCell& T, double x0, d
     }
     return false;
 }
-template <bool FILL>
+// the corners of rotated face f in axes (A0, A1) of the ray-cast frame
+template <int A0, int A1>
+__device__ __forceinline__ void face_corners2(const float4* __restrict__ rf, uint32_t f, float cr[6]) {
+    const float4 f0 = rf[3 * (size_t)f], f1 = rf[3 * (size_t)f + 1];
+    const float a[3] = {f0.x, f0.y, f0.z}, b[3] = {f0.w, f1.x, f1.y};
+    float c[3] = {f1.z, f1.w, 0.f};
+    if (A0 == 2 || A1 == 2) c[2] = rf[3 * (size_t)f + 2].x;
+    cr[0] = a[A0], cr[1] = a[A1], cr[2] = b[A0], cr[3] = b[A1], cr[4] = c[A0], cr[5] = c[A1];
+}
+// Axes (A0, A1) of the boxes / corners span the grid: (0, 1) for the z rays (and the renderer's image plane),
+// (1, 2) for the x+ ray.
+template <bool FILL, int A0, int A1>
 __global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridParams G,
                              uint32_t* __restrict__ cells /* counts | cursors */,
                              uint32_t* __restrict__ items, uint32_t* __restrict__ big,
@@ -595,7 +626,8 @@ __global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridPa
                              float4* __restrict__ ent /* FILL: two float4 per entry (see MeshDev::gr_ent), or nullptr */) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nf) return;
-    const float* b = fbox + 6 * (size_t)f;
+    const float* bf = fbox + 6 * (size_t)f;
+    const float b[5] = {bf[A0], bf[A1], 0.f, bf[3 + A0], bf[3 + A1]};  // (min at 0, 1; max at 3, 4)
     // Renderer: a face whose image-space box has a NaN is never inserted (renderer.cpp:52-56)
     if (skip_nan && (b[0] != b[0] || b[1] != b[1] || b[3] != b[3] || b[4] != b[4])) return;
     const int x0 = grid_cell(b[0], G.o0, G.inv0, G.g), x1 = grid_cell(b[3], G.o0, G.inv0, G.g);
@@ -608,7 +640,9 @@ __global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridPa
     if (rface && nc > 1u && wx > 0.0 && wy > 0.0) {
         // slack of the cell function (subtract, multiply, floor in fp32): a few ulps of the grid's span
         const double span = fabs((double)G.o0) + fabs((double)G.o1) + (double)G.g * (wx + wy);
-        T = tri_cell_setup(b, rface[3 * (size_t)f], rface[3 * (size_t)f + 1], 1e-6 * span);
+        float cr[6];
+        face_corners2<A0, A1>(rface, f, cr);
+        T = tri_cell_setup((double)b[3] - b[0], (double)b[4] - b[1], cr, 1e-6 * span);
     }
     if (nc > (T.on ? GRID_BIG_TRI : GRID_BIG)) {
         if (!FILL) big[atomicAdd(nbig, 1u)] = f;
@@ -625,10 +659,11 @@ __global__ void k_grid_faces(const float* __restrict__ fbox, uint32_t nf, GridPa
             if (FILL) {
                 const uint32_t slot = atomicAdd(&cells[c], 1u);
                 items[slot] = f;
-                if (ent) {  // the triangle in x', y' and the face id: what a ray needs before any per-face fetch
-                    const float4 f0 = ent_src[3 * (size_t)f], f1 = ent_src[3 * (size_t)f + 1];
-                    ent[2 * (size_t)slot] = make_float4(f0.x, f0.y, f0.w, f1.x);
-                    ent[2 * (size_t)slot + 1] = make_float4(f1.z, f1.w, __uint_as_float(f), 0.f);
+                if (ent) {  // the triangle in the grid's axes and the face id: what a ray needs before any per-face fetch
+                    float cr[6];
+                    face_corners2<A0, A1>(ent_src, f, cr);
+                    ent[2 * (size_t)slot] = make_float4(cr[0], cr[1], cr[2], cr[3]);
+                    ent[2 * (size_t)slot + 1] = make_float4(cr[4], cr[5], __uint_as_float(f), 0.f);
                 }
             } else {
                 atomicAdd(&cells[c], 1u);

@@ -52,6 +52,13 @@ struct MeshDev {
     int ray_lbvh;  // packet kernel: walk the LBVH cooperatively instead of the grid (long lists)
     int gr_g;
     float gr_o0, gr_o1, gr_inv0, gr_inv1;
+    // the same over (y', z') for the x+ tie-break ray (gx_start == nullptr: walk the LBVH instead)
+    const uint32_t* gx_start;
+    const float4* gx_ent;       // {a'.y, a'.z, b'.y, b'.z}, {c'.y, c'.z, face id, 0}
+    const uint32_t* gx_big;
+    uint32_t gx_nbig;
+    int gx_g;
+    float gx_o0, gx_o1, gx_inv0, gx_inv1;
     float R[9];
 };
 
@@ -216,11 +223,29 @@ __device__ __forceinline__ int kd_nearest(const MeshDev& M, float qx, float qy, 
 // The z+ and z- rays share (x,y), the facing dot product and bary2d, so they are one pass over
 // the column grid's candidates; the x+ tie-break ray walks the threaded LBVH.
 // =========================================================================================
-__device__ __forceinline__ int ray_x_pos(const MeshDev& M, V3 q) {
+#ifdef SDFK_STATS
+// queries in the box, faces tested, faces passing Overlap in xy, records fetched; x+ rays, their nodes, the longest
+// x+ walk (nodes), the longest cell list walked
+__device__ unsigned long long g_ray_stats[8];
+#define SDFK_RMAX(K, V) atomicMax(&g_ray_stats[K], (unsigned long long)(V))
+#define SDFK_RADD(K, V) atomicAdd(&g_ray_stats[K], (unsigned long long)(V))
+#define SDFK_RCOUNT(K) atomicAdd(&g_ray_stats[K], 1ull)
+#else
+#define SDFK_RCOUNT(K)
+#define SDFK_RMAX(K, V)
+#define SDFK_RADD(K, V)
+#endif
+__device__ __forceinline__ int ray_x_pos_lbvh(const MeshDev& M, V3 q) {
     int c = 0;
     uint32_t i = 0;
     const uint32_t n = M.n_rnodes;
+#ifdef SDFK_STATS
+    uint32_t visited = 0;
+#endif
     while (i < n) {
+#ifdef SDFK_STATS
+        ++visited;
+#endif
         const float4 a = M.rnodes[2 * (size_t)i];
         const float4 b = M.rnodes[2 * (size_t)i + 1];
         // box: x in [q.x, FLT_MAX], y and z pinned
@@ -245,6 +270,11 @@ __device__ __forceinline__ int ray_x_pos(const MeshDev& M, V3 q) {
         }
         i = i + 1;
     }
+#ifdef SDFK_STATS
+    SDFK_RCOUNT(4);
+    SDFK_RADD(5, visited);
+    SDFK_RMAX(6, visited);
+#endif
     return c;
 }
 
@@ -261,12 +291,6 @@ __device__ __forceinline__ int grid_cell(float v, float o, float inv, int g) {
     if (f >= (float)(g - 1)) return g - 1;
     return (int)f;
 }
-#ifdef SDFK_STATS
-__device__ unsigned long long g_ray_stats[4];  // queries in the box, faces tested, faces passing Overlap in xy, bary2d evaluated
-#define SDFK_RCOUNT(K) atomicAdd(&g_ray_stats[K], 1ull)
-#else
-#define SDFK_RCOUNT(K)
-#endif
 __device__ __forceinline__ void ray_face_z(const MeshDev& M, V3 q, uint32_t face, int& zp, int& zm) {
     const float* bx = M.fbox + 6 * (size_t)face;
     const float mnx = bx[0], mny = bx[1], mnz = bx[2], mxx = bx[3], mxy = bx[4], mxz = bx[5];
@@ -323,16 +347,17 @@ __device__ __forceinline__ float fmax3(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-// Overlap in x', y' and bary2d of one list entry (the face's corners in x', y').  The box is rebuilt from the
+// Overlap in the grid's two axes and bary2d of one list entry (the face's corners in those axes; (qx, qy):
+// the query in them).  The box is rebuilt from the
 // corners with v_min3 / v_max3: equal to the std::min / std::max chain of k_face_precompute for corners
 // without a NaN (up to the sign of a zero, which no comparison sees); with a NaN corner the two may differ,
 // and then bary2d is false (its denominator is NaN), which is all that a failed Overlap would have meant.
-__device__ __forceinline__ bool ray_entry_inside(V3 q, const float4 e0, const float4 e1) {
+__device__ __forceinline__ bool ray_entry_inside(float qx, float qy, const float4 e0, const float4 e1) {
     const float mnx = fmin3(e0.x, e0.z, e1.x), mxx = fmax3(e0.x, e0.z, e1.x);
     const float mny = fmin3(e0.y, e0.w, e1.y), mxy = fmax3(e0.y, e0.w, e1.y);
-    if ((q.x > mxx || mnx > q.x) || (q.y > mxy || mny > q.y)) return false;  // Overlap, x and y
+    if ((qx > mxx || mnx > qx) || (qy > mxy || mny > qy)) return false;  // Overlap in the two pinned axes
     SDFK_RCOUNT(2);
-    return sdfk::bary2d_inside(q.x, q.y, e0.x, e0.y, e0.z, e0.w, e1.x, e1.y);
+    return sdfk::bary2d_inside(qx, qy, e0.x, e0.y, e0.z, e0.w, e1.x, e1.y);
 }
 // The cell's list carries each face's corners in x', y' next to its id (cell-major, read as a stream, 32 B per
 // entry): Overlap in x, y and bary2d need nothing else, and only the faces the column really pierces (2-6 of
@@ -346,14 +371,15 @@ __device__ __forceinline__ void ray_z_pair_grid(const MeshDev& M, V3 q, int& zp,
     const int cx = grid_cell(q.x, M.gr_o0, M.gr_inv0, M.gr_g), cy = grid_cell(q.y, M.gr_o1, M.gr_inv1, M.gr_g);
     const uint32_t c = (uint32_t)cy * (uint32_t)M.gr_g + (uint32_t)cx;
     const uint32_t e = M.gr_start[c + 1];
+    SDFK_RMAX(7, e - M.gr_start[c]);
     for (uint32_t k = M.gr_start[c]; k < e; k += 2u) {
         const uint32_t k1 = k + 1u < e ? k + 1u : k;
         const float4 a0 = M.gr_ent[2 * (size_t)k], a1 = M.gr_ent[2 * (size_t)k + 1];
         const float4 b0 = M.gr_ent[2 * (size_t)k1], b1 = M.gr_ent[2 * (size_t)k1 + 1];
         SDFK_RCOUNT(1);
         if (k1 != k) SDFK_RCOUNT(1);
-        const bool in0 = ray_entry_inside(q, a0, a1);
-        const bool in1 = k1 != k && ray_entry_inside(q, b0, b1);
+        const bool in0 = ray_entry_inside(q.x, q.y, a0, a1);
+        const bool in1 = k1 != k && ray_entry_inside(q.x, q.y, b0, b1);
         const uint32_t i0 = __float_as_uint(a1.z), i1 = __float_as_uint(b1.z);
         float4 f00, f01, f02, f10, f11, f12;
         if (in0) f00 = M.rface[3 * (size_t)i0], f01 = M.rface[3 * (size_t)i0 + 1], f02 = M.rface[3 * (size_t)i0 + 2];
@@ -362,6 +388,46 @@ __device__ __forceinline__ void ray_z_pair_grid(const MeshDev& M, V3 q, int& zp,
         if (in1) ray_face_z_side(q, f10, f11, f12, zp, zm);
     }
     for (uint32_t k = 0; k < M.gr_nbig; ++k) ray_face_z(M, q, M.gr_big[k], zp, zm);
+}
+
+// The x+ tie-break ray (sdf.cpp:326) on its own column grid over (y', z'): the same walk as the z rays.  The
+// stackless LBVH walk it replaces met 1.5k (torus) to 21k (noisy icosphere-7) nodes per ray, one dependent
+// load after the other in a single lane: rare (a handful of rays per million queries on a closed mesh) but
+// each one kept its wave for up to 4 ms, the whole floor of a contains() call on a rough mesh.
+__device__ __forceinline__ void ray_face_x(const MeshDev& M, V3 q, uint32_t face, int& c) {  // big list
+    const float* bx = M.fbox + 6 * (size_t)face;
+    if (!(!(q.y > bx[4] || bx[1] > q.y) && !(q.z > bx[5] || bx[2] > q.z) && !(q.x > bx[3] || bx[0] > FLT_MAX))) return;
+    const float4 f0 = M.rface[3 * (size_t)face], f1 = M.rface[3 * (size_t)face + 1], f2 = M.rface[3 * (size_t)face + 2];
+    const V3 nr = {f2.y, f2.z, f2.w};
+    const V3 dv = sdfk::sub(q, V3{f0.x, f0.y, f0.z});
+    const float s = sdfk::dot(nr, dv) * nr.x;  // ax_idx = 0, ax_inv = false
+    if (!(s > 0.f))
+        if (sdfk::bary2d_inside(q.y, q.z, f0.y, f0.z, f1.x, f1.y, f1.w, f2.x)) c ^= 1;
+}
+__device__ __forceinline__ int ray_x_pos(const MeshDev& M, V3 q) {
+    if (!M.gx_start) return ray_x_pos_lbvh(M, q);
+    int c = 0;
+    const int cy = grid_cell(q.y, M.gx_o0, M.gx_inv0, M.gx_g), cz = grid_cell(q.z, M.gx_o1, M.gx_inv1, M.gx_g);
+    const uint32_t cell = (uint32_t)cz * (uint32_t)M.gx_g + (uint32_t)cy;
+    const uint32_t e = M.gx_start[cell + 1];
+    SDFK_RCOUNT(4);
+    SDFK_RADD(5, e - M.gx_start[cell]);
+    SDFK_RMAX(6, e - M.gx_start[cell]);
+    for (uint32_t k = M.gx_start[cell]; k < e; ++k) {
+        const float4 e0 = M.gx_ent[2 * (size_t)k], e1 = M.gx_ent[2 * (size_t)k + 1];
+        if (!ray_entry_inside(q.y, q.z, e0, e1)) continue;
+        // Overlap in y, z and bary2d hold: the x side of Overlap (box [q.x, FLT_MAX]) and the facing rule
+        const uint32_t face = __float_as_uint(e1.z);
+        const float4 f0 = M.rface[3 * (size_t)face], f1 = M.rface[3 * (size_t)face + 1], f2 = M.rface[3 * (size_t)face + 2];
+        const float mnx = sdfk::stdmin(sdfk::stdmin(f0.x, f0.w), f1.z), mxx = sdfk::stdmax(sdfk::stdmax(f0.x, f0.w), f1.z);
+        if (q.x > mxx || mnx > FLT_MAX) continue;
+        const V3 nr = {f2.y, f2.z, f2.w};
+        const V3 dv = sdfk::sub(q, V3{f0.x, f0.y, f0.z});
+        const float s = sdfk::dot(nr, dv) * nr.x;  // ax_idx = 0, ax_inv = false
+        if (!(s > 0.f)) c ^= 1;
+    }
+    for (uint32_t k = 0; k < M.gx_nbig; ++k) ray_face_x(M, q, M.gx_big[k], c);
+    return c;
 }
 
 // Wave-cooperative walk of the threaded LBVH for 64 Morton-adjacent queries (used instead of

@@ -204,6 +204,8 @@ struct sdfhip_ctx {
     float* d_fbox = nullptr;
     // column grid (rebuilt by every update: face boxes move)
     GridBuf grid;
+    GridBuf grid_x;  // over (y', z'): the x+ tie-break ray (opt_x_grid)
+    int64_t opt_x_grid = 1;
     // fast_nn mode (GPU-built vertex tree)
     int64_t opt_fast_nn = 0;   // applies at the next update
     bool fast_active = false;  // what the structures on the device currently are
@@ -229,6 +231,7 @@ struct sdfhip_ctx {
     // options
     int64_t opt_sort = 1, opt_sort_min = 8192, opt_chunk = 1 << 27;
     int64_t opt_sort_min_contains = 12000000;  // robust contains(): see run_query_t
+    int64_t opt_column_sort = 1;  // robust contains(): sort by column of the ray-cast frame (0: 3-D Morton order)
     hipStream_t stream = nullptr;  // internal stream for create/update and host entry points
     // host entry points: double-buffered device staging, copies on their own streams
     hipStream_t s_in = nullptr, s_out = nullptr;
@@ -369,7 +372,7 @@ void draw_rotation(sdfhip_ctx* h) {
 // when the faces are large against the cells).
 int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], const float hi[2],
                int skip_nan, hipStream_t s, const float4* d_rface = nullptr, int64_t max_per_face = 16,
-               const float4* d_ent_src = nullptr /* the rotated faces, when B.want_ent */) {
+               const float4* d_ent_src = nullptr /* the rotated faces, when B.want_ent */, bool yz = false) {
     if (n == 0) {  // no faces: one empty cell (the query kernels always look their cell up)
         if (B.cells_cap < 2) {
             if (int rc = dalloc(&B.start, 2)) return rc;
@@ -407,8 +410,12 @@ int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], c
         }
         HIPC(hipMemsetAsync(B.start, 0, sizeof(uint32_t) * cells, s));
         HIPC(hipMemsetAsync(B.nbig_dev, 0, sizeof(uint32_t), s));
-        k_grid_faces<false><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.start, nullptr, B.big,
-                                                            B.nbig_dev, skip_nan, d_rface, nullptr, nullptr);
+        if (yz)
+            k_grid_faces<false, 1, 2><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.start, nullptr, B.big,
+                                                                      B.nbig_dev, skip_nan, d_rface, nullptr, nullptr);
+        else
+            k_grid_faces<false, 0, 1><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.start, nullptr, B.big,
+                                                                      B.nbig_dev, skip_nan, d_rface, nullptr, nullptr);
         exclusive_scan_u32(B.start, (uint32_t)cells, B.s1, B.s2, s);
         uint32_t total = 0, nbig = 0;
         HIPC(hipMemcpyAsync(&total, B.start + (cells - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -428,8 +435,12 @@ int grid_build(GridBuf& B, const float* d_fbox, uint32_t n, const float lo[2], c
             B.items_cap = cap;
         }
         HIPC(hipMemcpyAsync(B.cursor, B.start, sizeof(uint32_t) * cells, hipMemcpyDeviceToDevice, s));
-        k_grid_faces<true><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.cursor, B.items, B.big,
-                                                           B.nbig_dev, skip_nan, d_rface, d_ent_src, B.want_ent ? B.ent : nullptr);
+        if (yz)
+            k_grid_faces<true, 1, 2><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.cursor, B.items, B.big, B.nbig_dev,
+                                                                     skip_nan, d_rface, d_ent_src, B.want_ent ? B.ent : nullptr);
+        else
+            k_grid_faces<true, 0, 1><<<(n + 255) / 256, 256, 0, s>>>(d_fbox, n, G, B.cursor, B.items, B.big, B.nbig_dev,
+                                                                     skip_nan, d_rface, d_ent_src, B.want_ent ? B.ent : nullptr);
         HIPC(hipGetLastError());
         B.gr = G;
         B.coarsened = long_lists;
@@ -509,7 +520,23 @@ int build_grid(sdfhip_ctx* h) {
         }
     }
     h->grid.want_ent = true;
-    return grid_build(h->grid, h->d_fbox, h->nf, lo, hi, 0, h->stream, h->opt_grid_tri ? h->d_rface : nullptr, h->opt_grid_per_face, h->d_rface);
+    if (int rc = grid_build(h->grid, h->d_fbox, h->nf, lo, hi, 0, h->stream, h->opt_grid_tri ? h->d_rface : nullptr,
+                            h->opt_grid_per_face, h->d_rface))
+        return rc;
+    if (!h->opt_x_grid) return 0;
+    // the x+ tie-break ray's own grid over (y', z')
+    float lo2[2] = {FLT_MAX, FLT_MAX}, hi2[2] = {-FLT_MAX, -FLT_MAX};
+    for (int c = 0; c < 8; ++c) {
+        const float x = h->aabb[(c & 1) ? 3 : 0], y = h->aabb[(c & 2) ? 4 : 1], z = h->aabb[(c & 4) ? 5 : 2];
+        for (int d = 0; d < 2; ++d) {
+            const float r = x * h->R[d + 1] + y * h->R[3 + d + 1] + z * h->R[6 + d + 1];
+            lo2[d] = r < lo2[d] ? r : lo2[d];
+            hi2[d] = r > hi2[d] ? r : hi2[d];
+        }
+    }
+    h->grid_x.want_ent = true;
+    return grid_build(h->grid_x, h->d_fbox, h->nf, lo2, hi2, 0, h->stream, h->opt_grid_tri ? h->d_rface : nullptr,
+                      h->opt_grid_per_face, h->d_rface, true);
 }
 
 // rotation-dependent + vertex-dependent precompute; verts must already be in d_verts
@@ -804,6 +831,13 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
                      ? 1
                      : 0;
     M.gr_o0 = h->grid.gr.o0, M.gr_o1 = h->grid.gr.o1, M.gr_inv0 = h->grid.gr.inv0, M.gr_inv1 = h->grid.gr.inv1;
+    const bool xg = h->robust && h->opt_x_grid && h->grid_x.start;
+    M.gx_start = xg ? h->grid_x.start : nullptr;
+    M.gx_ent = h->grid_x.ent;
+    M.gx_big = h->grid_x.big;
+    M.gx_nbig = xg ? h->grid_x.nbig : 0;
+    M.gx_g = h->grid_x.gr.g;
+    M.gx_o0 = h->grid_x.gr.o0, M.gx_o1 = h->grid_x.gr.o1, M.gx_inv0 = h->grid_x.gr.inv0, M.gx_inv1 = h->grid_x.gr.inv1;
     for (int d = 0; d < 9; ++d) M.R[d] = h->R[d];
     return M;
 }
@@ -1014,15 +1048,24 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         void* o = (char*)d_out + osz * (size_t)off;
         const uint32_t* perm = nullptr;
         if (h->opt_sort && m >= sort_min) {
-            k_bounds_init<<<1, 64, 0, s>>>(W.qbounds);
-            // large batches: the bounds come from a strided sample (1/16 of the points, in 3 KB runs)
-            const int sample = m >= (8 << 20) ? 16 : 1;
-            const int64_t groups = m / 4 / sample;
-            const int nb = (int)((groups + 255) / 256 < 1024 ? (groups + 255) / 256 + 1 : 1024);
-            k_bounds<<<nb, 256, 0, s>>>(p, m, W.qbounds, sample);
+            // robust contains() is rays only: its queries are ordered by column of the ray-cast frame
+            ColumnKey CK = {};
+            if (KIND == Q_CONTAINS && ROBUST && h->opt_column_sort) {
+                CK.on = 1;
+                for (int d = 0; d < 3; ++d) CK.r0[d] = M.R[3 * d], CK.r1[d] = M.R[3 * d + 1];
+                CK.o0 = M.gr_o0, CK.o1 = M.gr_o1;
+                CK.s0 = M.gr_inv0 * (4096.f / (float)M.gr_g), CK.s1 = M.gr_inv1 * (4096.f / (float)M.gr_g);
+            } else {
+                k_bounds_init<<<1, 64, 0, s>>>(W.qbounds);
+                // large batches: the bounds come from a strided sample (1/16 of the points, in 3 KB runs)
+                const int sample = m >= (8 << 20) ? 16 : 1;
+                const int64_t groups = m / 4 / sample;
+                const int nb = (int)((groups + 255) / 256 < 1024 ? (groups + 255) / 256 + 1 : 1024);
+                k_bounds<<<nb, 256, 0, s>>>(p, m, W.qbounds, sample);
+            }
             if (int rc = W.sorter.reserve((uint32_t)m)) return rc;  // (the key kernel fills its first histogram)
             const uint32_t ntiles = (uint32_t)((m + RS_TILE - 1) / RS_TILE);
-            k_query_morton<<<ntiles, RS_THREADS, 0, s>>>(p, (uint32_t)m, W.qbounds, W.qkeys, W.sorter.hist, ntiles);
+            k_query_morton<<<ntiles, RS_THREADS, 0, s>>>(p, (uint32_t)m, W.qbounds, W.qkeys, W.sorter.hist, ntiles, CK);
             uint32_t* sorted_perm = nullptr;
             if (int rc = W.sorter.sort(W.qkeys, W.qperm, (uint32_t)m, 24, 1, s, nullptr, &sorted_perm, false, true))
                 return rc;
@@ -1473,6 +1516,7 @@ void sdfhip_destroy(sdfhip_t* h) {
     h->ws.sorter.release();
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     h->grid.release();
+    h->grid_x.release();
     for (int k = 0; k < 2; ++k) {
         if (h->d_stage_in[k]) (void)hipFree(h->d_stage_in[k]);
         if (h->d_stage_out[k]) (void)hipFree(h->d_stage_out[k]);
@@ -1705,11 +1749,11 @@ int sdfhip_sample_surface(sdfhip_t* h, int64_t n, uint64_t seed, float* out) {
     return rc;
 }
 #ifdef SDFK_STATS
-int sdfhip_debug_ray_stats(unsigned long long out[4], int reset) {
+int sdfhip_debug_ray_stats(unsigned long long out[8], int reset) {
     HIPC(hipDeviceSynchronize());
-    HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_stats), 4 * sizeof(unsigned long long)));
+    HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_stats), 8 * sizeof(unsigned long long)));
     if (reset) {
-        unsigned long long z[4] = {0, 0, 0, 0};
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIPC(hipMemcpyToSymbol(HIP_SYMBOL(g_ray_stats), z, sizeof(z)));
     }
     return 0;
@@ -1789,6 +1833,10 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_sort_min = v;
     else if (!strcmp(key, "sort_min_contains"))
         h->opt_sort_min_contains = v;
+    else if (!strcmp(key, "column_sort"))
+        h->opt_column_sort = v ? 1 : 0;
+    else if (!strcmp(key, "x_grid"))
+        h->opt_x_grid = v ? 1 : 0;  // from the next update on (0: the x+ ray walks the LBVH)
     else if (!strcmp(key, "chunk")) {
         if (v < 1024 || v > (1ll << 27)) return fail(SDFHIP_E_INVALID, "chunk must be in [1024, 2^27]");
         h->opt_chunk = v;

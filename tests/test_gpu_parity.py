@@ -164,6 +164,32 @@ def test_ray_grid_big_faces_and_coarsening():
             assert same_float(s(p[:50000]), o(p[:50000])).all()
 
 
+@pytest.mark.parametrize("x_grid", [1, 0])
+def test_open_meshes_x_tiebreak_ray(x_grid):
+    """z+ and z- disagree wherever a mesh is not closed, and the x+ ray decides (sdf.cpp:326): on its own
+    column grid over (y', z') (default) or on the LBVH (x_grid = 0), same parities as the oracle per ray"""
+    rng = np.random.default_rng(31)
+    R = meshes.random_rotation(6)
+    vt, ft = meshes.torus(90, 90)
+    ft = ft[rng.uniform(size=ft.shape[0]) > 0.3]  # a torus with 30 % of its faces missing
+    vn, fn = meshes.icosphere(5, radius=0.7, noise=0.05, seed=2)
+    fn = fn[rng.uniform(size=fn.shape[0]) > 0.1]  # a rough sphere with holes
+    for v, f in ((vt, ft), (vn, fn)):
+        f = np.ascontiguousarray(f)
+        o = po.OracleSDF(v, f, True, R)
+        s = SDF(v, f)
+        s.set_option("x_grid", x_grid)
+        s.set_raycast_axes(R)
+        p = rng.uniform(-1, 1, (120_000, 3)).astype(np.float32)
+        p[:1500] = v[rng.integers(0, v.shape[0], 1500)]
+        want = o.raycast_detail(p)
+        assert (want[:, 2] >= 0).sum() > 3000  # the x+ ray really is cast
+        assert (s.raycast_detail(p) == want).all()
+        s.set_option("sort_min_contains", 0)
+        assert (s.contains(p) == o.contains(p)).all()
+        assert same_float(s(p), o(p)).all()
+
+
 def test_degenerate_vertex_sets_use_deep_trees():
     """geometric vertex sequence -> very deep nanoflann tree -> global-memory stack variant"""
     rng = np.random.default_rng(2)

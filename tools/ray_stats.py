@@ -17,10 +17,11 @@ s = sdf_amd.SDF(v, f, robust=True)
 s.set_raycast_axes(meshes.random_rotation(1234))
 s.set_option("ray_mode", a.ray_mode)
 pts = torch.rand((a.n, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)).mul_(2).sub_(1)
-st = (C.c_ulonglong * 4)()
+st = (C.c_ulonglong * 8)()
 s._L.sdfhip_debug_ray_stats(st, 1)
 s.contains(pts); torch.cuda.synchronize()
 s._L.sdfhip_debug_ray_stats(st, 1)
 q = max(1, st[0])
 print(f"{a.mesh} noise {a.noise} faces {f.shape[0]}: queries in box {st[0]} ({st[0]/a.n:.2f} of all); per such query: "
-      f"faces tested {st[1]/q:.1f}  pass Overlap xy (bary2d evaluated) {st[2]/q:.1f}  inside the triangle (record fetched) {st[3]/q:.1f}")
+      f"faces tested {st[1]/q:.1f}  pass Overlap xy (bary2d evaluated) {st[2]/q:.1f}  inside the triangle (record fetched) {st[3]/q:.1f}\n"
+      f"  x+ tie-break rays {st[4]} ({st[4]/q:.4f} per query), nodes per x+ ray {st[5]/max(1,st[4]):.0f}, longest x+ walk {st[6]} nodes, longest cell list {st[7]}")
