@@ -176,7 +176,11 @@ def main():
     # command, tools/collect_profiles.sh -> profiles/*_pmc.json); cannot be read live
     try:
         import glob
-        pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+        def round_of(f):  # profiles/r02_pmc.json -> (2, 1); r02a_pmc.json (mid-round) -> (2, 0)
+            tag = os.path.basename(f).split("_")[0]
+            digits = "".join(ch for ch in tag if ch.isdigit())
+            return (int(digits or 0), 1 if tag[-1:].isdigit() else 0)
+        pj = max(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), key=round_of)
         pm = json.load(open(pj))
         if pm.get("traffic_bytes_per_launch") and n == 125_000_000 and not a.no_sort:
             # NOT measured by this run: PMC counters need their own rocprofv3 passes

@@ -265,7 +265,7 @@ int sdfhip_host_free(void* p);
 
 /* Tuning knobs (no counterpart). key: "sort_queries" (0/1, default 1: Morton-sort query
  * chunks of >= sort_min points), "sort_min", "sort_min_contains" (the same threshold for robust contains(),
- * default 12M: below it the ray walk runs on the caller's order), "chunk" (points per internal chunk), "packet" (0: strict kernel only),
+ * default -1 = automatic: from 1M points on when the column grid's cells hold more than 20 faces on average, never otherwise; below it the ray walk runs on the caller's order), "chunk" (points per internal chunk), "packet" (0: strict kernel only),
  * "approx" (packet pass: approximate first pass + exact second phase; -1 automatic (default), 0 off, 1 on; results are identical either way),
  * "scan_max" (batches with points x padded vertices up to this value are answered by the exact one-wave-per-query
  * scan instead of a tree walk; -1 = automatic (the default: ~5e8 x (vertices / 4000)^0.57), 0 = never), "heavy_budget" (chunks of four vertices a wave of the packet pass may evaluate before its queries go
@@ -274,7 +274,13 @@ int sdfhip_host_free(void* p);
  * reference's first-visited one), "packet_group" (vertices per leaf group of the packet pass, 10..60, 0 = automatic: 40 with the approximate first pass, else 24; applies at the next update), "host_chunk" (points per
  * staging slot of the host entry points, 0 = automatic),
  * "build_threads" (host threads of the kd-tree build; default min(cores, OMP_NUM_THREADS, 16)), "profile" (1: time every query kernel launch
- * with hipEvents on its stream, read back through sdfhip_get_stats; 2: same and reset). */
+ * with hipEvents on its stream, read back through sdfhip_get_stats; 2: same and reset),
+ * "ray_mode" (0 automatic, 1 column grid, 2 cooperative LBVH walk for the z rays), "grid_tri" (0/1: triangle filter of the column
+ * grid's cells), "grid_per_face" (list entries per face beyond which the grid coarsens), "x_grid" (0/1, applies at the next
+ * update: the x+ tie-break ray reads its own column grid over (y', z') instead of walking the LBVH), "column_sort" (0/1: robust
+ * contains() sorts its queries by column of the ray-cast frame instead of 3-D Morton order), "coop_budget" (work units after
+ * which a packet's walk is continued by eight waves, 0 = never; default 1500), "coop_max" (largest launch, in points, that
+ * uses it; default 2^24).  No option changes a result, except "fast_nn" as described. */
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t value);
 
 const char* sdfhip_last_error(void);

@@ -230,7 +230,7 @@ struct sdfhip_ctx {
     size_t gstack_words = 0;
     // options
     int64_t opt_sort = 1, opt_sort_min = 8192, opt_chunk = 1 << 27;
-    int64_t opt_sort_min_contains = 12000000;  // robust contains(): see run_query_t
+    int64_t opt_sort_min_contains = -1;  // robust contains(): -1 automatic, see run_query_t
     int64_t opt_column_sort = 1;  // robust contains(): sort by column of the ray-cast frame (0: 3-D Morton order)
     hipStream_t stream = nullptr;  // internal stream for create/update and host entry points
     // host entry points: double-buffered device staging, copies on their own streams
@@ -941,13 +941,17 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
     QueryWs& W = *h->W;
     const size_t osz = KIND == Q_CONTAINS ? 1 : (KIND == Q_DETAIL ? 12 : 4);
     const int64_t chunk = h->opt_chunk > 0 ? h->opt_chunk : (1 << 24);
-    // Robust contains() is the ray walk only (per-lane O(1) grid lookups): sorting buys it cache
-    // locality, not wave coherence, and pays off from ~12M points on (measured crossover 11M:
-    // 4M points 0.84 ms unsorted vs 1.06 ms sorted, 64M points 9.1 vs 7.3 ms).
+    // Robust contains() is the ray walk only (per-lane O(1) grid lookups): sorting (by column, see ColumnKey)
+    // buys it shared cell lists, nothing else, and costs ~0.025 ms per million points.  It pays when the lists
+    // are long (noisy icosphere-7, 43 entries per cell: 8M points 1.66 against 4.92 ms unsorted, 32M 5.1
+    // against 19.1) and never when they are short (424^2 torus, 9 per cell: 32M points 2.30 against 1.63 ms
+    // unsorted) — automatic: from 1M points on if the cells hold more than 20 entries on average.
     // (Not when the cooperative LBVH walk serves the rays: that one lives on coherent waves.)
-    const int64_t sort_min = (KIND == Q_CONTAINS && ROBUST && !M.ray_lbvh &&
-                              h->opt_sort_min_contains > h->opt_sort_min)
-                                 ? h->opt_sort_min_contains
+    const int64_t cells = (int64_t)h->grid.gr.g * h->grid.gr.g;
+    const int64_t contains_min = h->opt_sort_min_contains >= 0 ? h->opt_sort_min_contains
+                                 : ((int64_t)h->grid.entries > 20 * cells ? (1ll << 20) : (1ll << 62));
+    const int64_t sort_min = (KIND == Q_CONTAINS && ROBUST && !M.ray_lbvh && contains_min > h->opt_sort_min)
+                                 ? contains_min
                                  : h->opt_sort_min;
     const bool sort_any = h->opt_sort && n >= sort_min;
     // packet stack: <= 3 deferred slots per 4-wide level (+ the transient 4th); 132 B per slot
