@@ -696,7 +696,9 @@ __device__ __forceinline__ void packet_finish(const MeshDev& M, V3 p, bool valid
     if (APPROX) {
         // what the approximate pass cannot settle (a fourth candidate group, no finite distance, a
         // window the path check does not clear) goes to the exact scan of k_query_heavy, which
-        // takes the same decision with exact (b, s, h) and defers to the strict kernel itself
+        // takes the same decision with exact (b, s, h) and defers to the strict kernel itself.
+        // (Straight to the strict kernel's list instead, tried on a 1M-vertex mesh where the scan is a pass
+        // over 1.3M positions per query: 18k queries took 35 ms there against 16 ms in the scan.)
         if (valid && amb) heavy_list[atomicAdd(heavy_cnt, 1u)] = off + (uint32_t)src;
         if ((threadIdx.x & 63) == 0) amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
     } else {   // ambiguous lanes of this wave, in sorted order: compacted (stably) by k_fb_compact so

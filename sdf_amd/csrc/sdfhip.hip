@@ -670,10 +670,13 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     // Packet groups: a slot of the approximate pass costs 3.5 VALU against 10 of the exact walk, so
     // larger groups (fewer quad nodes, box tests and sorted inserts per wave) pay there.  Measured on
     // the 424^2 torus, groups of 24 / 40 / 60: 64M random points sdf 16.8 / 16.3 / 16.9 ms, 256^3 grid
-    // nn 5.1 / 4.6 / 4.8 ms, 4M points nn 2.8 / 2.6 / 2.6 ms (the exact walk was tuned to 24).
+    // nn 5.1 / 4.6 / 4.8 ms, 4M points nn 2.8 / 2.6 / 2.6 ms.  The exact walk was tuned to 24 on the 4-wide tree;
+    // on the wide walk (costs per group, not per vertex) 40 is better there too from ~50k vertices on
+    // (24 / 40: 424^2 torus nn 64M 13.8 / 13.1 ms, icosphere-7 32M 9.3 / 8.5, 1M-vertex torus 32M 39.1 / 31.5;
+    // 6.9k-vertex torus, 256^3 grid 1.85 / 2.03).
     h->kd.group_max = h->opt_packet_group > 0
                           ? (uint32_t)h->opt_packet_group
-                          : ((h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0) ? 40u : 24u);
+                          : (((h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0) || h->nv >= 50000u) ? 40u : 24u);
     if (h->robust && draw_R && !h->R_pinned) draw_rotation(h);
     // Device side (vertex upload, per-face precompute, LBVH order / refit) does not depend on
     // the kd-tree: it runs from a helper thread while this thread builds the tree.
