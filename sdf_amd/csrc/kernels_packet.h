@@ -8,12 +8,10 @@
 //
 // Far-field queries make nanoflann's per-query search visit ~100 leaves / ~500 vertices, and
 // 64 independent lanes doing that diverge badly (29 % VALU lane utilisation measured).  Here
-// the traversal is wave-uniform: the node stream is read with scalar loads, the stack is one
-// small LDS array per wave, every lane evaluates every visited vertex (no divergence).  A
-// subtree is skipped only when, for every lane, the tight box of its vertices is farther
-// than the lane's current best * c:  LB = ((gx^2+gy^2)+gz^2) with g = per-axis gap to the
-// box is a rigorous lower bound of every computed vertex distance in that box (rounding is
-// monotone and the association equals the metric's, nanoflann.hpp:432-440).
+// the traversal is wave-uniform (see "Wide packet walk" below): vertex groups come in by scalar
+// loads and every lane evaluates every visited vertex (no divergence).  A group is skipped only
+// when, for every lane, a rigorous lower bound of the distance to its box exceeds the lane's
+// current best * c (with slack for every rounding on the way).
 //
 // What this pass knows exactly per lane when it ends: the global fp32 minimum `best`, its
 // (first found) vertex `holder`, and `second` = the smallest distance found that is >= best
@@ -161,7 +159,7 @@ __device__ __forceinline__ float wave_readf(float v, uint32_t l) {
 // Wide packet walk.  The vertices' packet groups (maximal kd subtrees of <= group_max vertices, in
 // position order) are bounded by ORIENTED boxes: the vertices lie on a surface, a patch of it is
 // nearly flat, and an oriented box follows the patch where an axis-aligned one is as thick as the
-// patch is wide (measured with tools/obb_probe.cpp on the 424^2 torus: 2.6x fewer vertex slots per
+// patch is wide (measured with a host-side model of the walk on the 424^2 torus: 2.6x fewer vertex slots per
 // wave than the 4-wide tree of axis-aligned boxes this replaces).  Two levels, 64 children each:
 // an L1 node is a run of 64 consecutive groups.  A node is tested against the PACKET by all lanes
 // at once — lane k tests child k against the sphere around the wave's 64 queries — so a level
@@ -174,7 +172,7 @@ __device__ __forceinline__ float wave_readf(float v, uint32_t l) {
 //   lane level     f0 + n.(q_l - c) > sqrt(thr_l)  for every lane  =>  the same, where the half space
 //                  {x : n.(x - c) <= -f0}, |n| <= 1, contains B (n = direction from B to c, f0 from
 //                  the support function of B): a plane bound that is nearly as sharp as the exact
-//                  per-lane box distance (obb_probe: 8.1 against 7.4 groups per wave) for 4 readlanes
+//                  per-lane box distance (same model: 8.1 against 7.4 groups per wave) for 4 readlanes
 //                  and 3 FMAs per candidate.
 // Rounding: box records are fp32; the half extents are computed against the STORED centre and axes
 // and rounded up (k_group_obb), the projections' absolute error (<= 8u |c - c_B|) is covered by Ew

@@ -668,7 +668,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     h->kd.bounds(h->h_verts, h->nv, (int)h->opt_build_threads, h->aabb);
     h->approx_ok = approx_pays(h);
     // Packet groups: a slot of the approximate pass costs 3.5 VALU against 10 of the exact walk, so
-    // larger groups (fewer quad nodes, box tests and sorted inserts per wave) pay there.  Measured on
+    // larger groups (fewer box tests and sorted inserts per wave) pay there.  Measured on
     // the 424^2 torus, groups of 24 / 40 / 60: 64M random points sdf 16.8 / 16.3 / 16.9 ms, 256^3 grid
     // nn 5.1 / 4.6 / 4.8 ms, 4M points nn 2.8 / 2.6 / 2.6 ms.  The exact walk was tuned to 24 on the 4-wide tree;
     // on the wide walk (costs per group, not per vertex) 40 is better there too from ~50k vertices on
@@ -778,7 +778,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("SDFHIP_DEBUG")) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "[sdfhip] update %.2f ms: pre %.2f kd %.2f quads+fill %.2f wait-device %.2f upload %.2f\n",
+        std::fprintf(stderr, "[sdfhip] update %.2f ms: pre %.2f kd %.2f groups+fill %.2f wait-device %.2f upload %.2f\n",
                      h->last_update_ms, ms(t0, tk), h->last_kd_ms, ms(tq0, tq1), ms(tq1, tq2),
                      ms(tq2, std::chrono::steady_clock::now()));
     }
@@ -957,7 +957,6 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
                                  ? contains_min
                                  : h->opt_sort_min;
     const bool sort_any = h->opt_sort && n >= sort_min;
-    // packet stack: <= 3 deferred slots per 4-wide level (+ the transient 4th); 132 B per slot
     const bool fast = h->fast_active;  // GPU-built tree: the packet kernel is the only nn search
     // Small batches.  A tree walk is a chain of dependent loads: ~2 ms for ONE far-field query on a
     // 180k-vertex tree, whether a lane walks alone (strict kernel) or a wave walks for 64 sparse
@@ -1417,6 +1416,10 @@ static int create_impl(const float* verts, uint32_t nv, const uint32_t* faces, u
     if (const char* e = getenv("SDFHIP_APPROX")) {  // default of option "approx" (tests run both packet walks)
         const long long v = atoll(e);
         h->opt_approx = v < 0 ? -1 : (v ? 1 : 0);
+    }
+    if (const char* e = getenv("SDFHIP_COOP_BUDGET")) {  // default of option "coop_budget" (tuning: internal handles too)
+        const long long v = atoll(e);
+        h->opt_coop_budget = v < 0 ? 0 : v;
     }
     if (const char* e = getenv("SDFHIP_SCAN_MAX")) {  // default of option "scan_max" (tests pin the tree paths with 0)
         const long long v = atoll(e);
