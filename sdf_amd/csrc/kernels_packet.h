@@ -212,12 +212,12 @@ __device__ __forceinline__ ObbLane obb_wide(const float4* __restrict__ rec, uint
         o.nx = __builtin_fmaf(s0, B.x, __builtin_fmaf(s1, C.x, s2 * D.x));
         o.ny = __builtin_fmaf(s0, B.y, __builtin_fmaf(s1, C.y, s2 * D.y));
         o.nz = __builtin_fmaf(s0, B.z, __builtin_fmaf(s1, C.z, s2 * D.z));
-        // f0 = n.(c - c_B) - max_{x in B} n.(x - c_B) = n.(c - c_B) - sum_a h_a |n.R_a|
-        const float m0 = __builtin_fmaf(o.nx, B.x, __builtin_fmaf(o.ny, B.y, o.nz * B.z));
-        const float m1 = __builtin_fmaf(o.nx, C.x, __builtin_fmaf(o.ny, C.y, o.nz * C.z));
-        const float m2 = __builtin_fmaf(o.nx, D.x, __builtin_fmaf(o.ny, D.y, o.nz * D.z));
-        const float sup = __builtin_fmaf(A.w, fabsf(m0), __builtin_fmaf(B.w, fabsf(m1), C.w * fabsf(m2)));
-        o.f0 = __builtin_fmaf(o.nx, dx, __builtin_fmaf(o.ny, dy, o.nz * dz)) - (sup + 4.f * Ew);
+        // f0 = n.(c - c_B) - max_{x in B} n.(x - c_B) = n.(c - c_B) - sum_a h_a |n.R_a|.  The stored axes are
+        // orthonormal up to rounding (|R_a.R_b - delta_ab| <= 2.1u, n itself carries <= 3u |s|_1 per component),
+        // so |n.R_a - s_a| <= 5.1u |s|_1 <= 9u: s_a stands for n.R_a (9 FMAs less per test) and the difference,
+        // <= 27u x the largest half extent < Ew / 2, is one more Ew of slack.
+        const float sup = __builtin_fmaf(A.w, fabsf(s0), __builtin_fmaf(B.w, fabsf(s1), C.w * fabsf(s2)));
+        o.f0 = __builtin_fmaf(o.nx, dx, __builtin_fmaf(o.ny, dy, o.nz * dz)) - (sup + 5.f * Ew);
         // for every lane l:  f0 + n.e_l - rr_l  =  f0 + (n - g).e_l - (rr_l - g.e_l)  >=  pk - max_l (rr_l - g.e_l)
         // with |(n - g).e_l| <= sum_i |n_i - g_i| h_i, h = half extents of the queries' bounding box (rounded up)
         o.pk = o.f0 - __builtin_fmaf(fabsf(o.nx - gx), hx, __builtin_fmaf(fabsf(o.ny - gy), hy, fabsf(o.nz - gz) * hz));
@@ -530,7 +530,10 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
 }
 
 // exact evaluation of one packet group for one lane (second phase of the approximate pass): the
-// reference's metric, strict `<`, and among exact ties the vertex nanoflann's DFS meets first
+// reference's metric, strict `<`, and among exact ties the vertex nanoflann's DFS meets first.
+// TIES = false leaves the tie rule out (pos = the first vertex met at the minimum): valid whenever the
+// result has s2 > b, i.e. the minimum is unique; the caller redoes the lane with TIES = true otherwise.
+template <bool TIES>
 __device__ __forceinline__ void exact_group(const MeshDev& M, float qx, float qy, float qz, uint32_t ref,
                                             uint32_t& b, uint32_t& s2, uint32_t& pos) {
     const uint32_t first = ((ref & sdfk::KD_REF_MASK) >> 4) << 2, nch = ref & 15u;
@@ -548,7 +551,7 @@ __device__ __forceinline__ void exact_group(const MeshDev& M, float qx, float qy
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
             const uint32_t idx = first + 4u * c + j;
-            if (__builtin_expect(du[j] == b && pos != H_NONE, 0)) {
+            if (TIES && __builtin_expect(du[j] == b && pos != H_NONE, 0)) {
                 if ((uint32_t)kd_dfs_first(M, qx, qy, qz, (int)pos, (int)idx) == idx) pos = idx;
             }
             s2 = min(s2, max(du[j], b));
@@ -664,12 +667,21 @@ __device__ __forceinline__ void packet_finish(const MeshDev& M, V3 p, bool valid
         const float U = fmaxf(fmaxf(x1 * k1p, x1), 0.f);  // >= D of B1's vertex >= the exact minimum
         const float y2 = (A.B2 + Qf) - Ea, y3 = (A.B3 + Qf) - Ea, y4 = (A.B4 + Qf) - Ea;
         const float L2 = fminf(y2 * k1m, y2), L3 = fminf(y3 * k1m, y3), L4 = fminf(y4 * k1m, y4);  // <= D outside
+        // (Widening these tests to the window of the near-tie test below, so that a group's lower bound never
+        // stands in for `s` there, was measured: near-tie lanes 2.28 -> 2.18 per wave, step 22.4 -> 23.0 ms.  The
+        // near ties are real: far-field squared distances of neighbouring vertices differ by ~1e-5 relative.)
         const bool n2 = !(L2 > U), n3 = n2 && !(L3 > U), n4 = n3 && !(L4 > U);
         uint32_t b = 0x7F7FFFFFu, s2 = 0x7F7FFFFFu, hp = H_NONE;
         if (A.H1 != H_NONE && !n4) {
-            exact_group(M, p.x, p.y, p.z, A.H1, b, s2, hp);
-            if (n2) exact_group(M, p.x, p.y, p.z, A.H2, b, s2, hp);
-            if (n3) exact_group(M, p.x, p.y, p.z, A.H3, b, s2, hp);
+            exact_group<false>(M, p.x, p.y, p.z, A.H1, b, s2, hp);
+            if (n2) exact_group<false>(M, p.x, p.y, p.z, A.H2, b, s2, hp);
+            if (n3) exact_group<false>(M, p.x, p.y, p.z, A.H3, b, s2, hp);
+            if (__builtin_expect(s2 == b && hp != H_NONE, 0)) {  // an exact tie at the minimum: again, with the tie rule
+                b = 0x7F7FFFFFu, s2 = 0x7F7FFFFFu, hp = H_NONE;
+                exact_group<true>(M, p.x, p.y, p.z, A.H1, b, s2, hp);
+                if (n2) exact_group<true>(M, p.x, p.y, p.z, A.H2, b, s2, hp);
+                if (n3) exact_group<true>(M, p.x, p.y, p.z, A.H3, b, s2, hp);
+            }
         }
         const float s_out = n3 ? L4 : (n2 ? L3 : L2);  // every vertex outside the evaluated groups is farther
         pb.b = __uint_as_float(b);
