@@ -225,6 +225,8 @@ struct sdfhip_ctx {
     LbvhTopo topo{};
     uint32_t bvh_depth = 0;
     bool topo_built = false;
+    bool lbvh_valid = false;   // rnodes hold the current face boxes (built only when something walks the LBVH)
+    bool xgrid_built = false;  // grid_x is current (the x+ ray reads it)
     float topo_R[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // rotation the LBVH topology was built for
     uint32_t* d_gstack = nullptr;  // strict kernel, trees deeper than LDS_DEPTH_MAX
     size_t gstack_words = 0;
@@ -520,6 +522,7 @@ int build_grid(sdfhip_ctx* h) {
         }
     }
     h->grid.want_ent = true;
+    h->xgrid_built = false;
     if (int rc = grid_build(h->grid, h->d_fbox, h->nf, lo, hi, 0, h->stream, h->opt_grid_tri ? h->d_rface : nullptr,
                             h->opt_grid_per_face, h->d_rface))
         return rc;
@@ -535,8 +538,28 @@ int build_grid(sdfhip_ctx* h) {
         }
     }
     h->grid_x.want_ent = true;
-    return grid_build(h->grid_x, h->d_fbox, h->nf, lo2, hi2, 0, h->stream, h->opt_grid_tri ? h->d_rface : nullptr,
-                      h->opt_grid_per_face, h->d_rface, true);
+    if (int rc = grid_build(h->grid_x, h->d_fbox, h->nf, lo2, hi2, 0, h->stream, h->opt_grid_tri ? h->d_rface : nullptr,
+                            h->opt_grid_per_face, h->d_rface, true))
+        return rc;
+    h->xgrid_built = true;
+    return 0;
+}
+
+// Does anything walk the LBVH?  The z rays in ray mode 2 (or when the automatic rule picks it, see mesh_view),
+// the x+ ray without its grid.  Otherwise the LBVH is neither ordered nor refit by update() (0.3 ms of 2.6).
+bool lbvh_rule(const sdfhip_ctx* h) {
+    return h->opt_ray_mode == 2 ||
+           (h->opt_ray_mode == 0 && (h->grid.nbig > 64u || (h->grid.coarsened && !h->opt_grid_tri)));
+}
+bool wants_lbvh(const sdfhip_ctx* h) { return lbvh_rule(h) || !h->xgrid_built; }
+int ensure_lbvh(sdfhip_ctx* h) {
+    if (h->lbvh_valid) return 0;
+    // the face order follows the ray-cast frame: rebuilt when R changed, refit otherwise
+    if (!h->topo_built || std::memcmp(h->topo_R, h->R, sizeof(h->topo_R)) != 0)
+        if (int rc = build_topology(h)) return rc;
+    if (int rc = refit(h)) return rc;
+    h->lbvh_valid = true;
+    return 0;
 }
 
 // rotation-dependent + vertex-dependent precompute; verts must already be in d_verts
@@ -552,11 +575,10 @@ int update_device_side(sdfhip_ctx* h) {
     h->h_face_valid = false;
     h->cum_valid = false;
     if (h->robust) {
-        // the face order follows the ray-cast frame: rebuilt when R changed, refit otherwise
-        if (!h->topo_built || std::memcmp(h->topo_R, h->R, sizeof(h->topo_R)) != 0)
-            if (int rc = build_topology(h)) return rc;
-        if (int rc = refit(h)) return rc;
+        h->lbvh_valid = false;
         if (int rc = build_grid(h)) return rc;
+        if (wants_lbvh(h))
+            if (int rc = ensure_lbvh(h)) return rc;
     }
     return 0;
 }
@@ -816,7 +838,7 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.adj_faces = h->d_adj_faces;
     M.geo = h->d_geo;
     M.rnodes = h->d_rnodes;
-    M.n_rnodes = h->robust ? h->n_rnodes : 0;
+    M.n_rnodes = h->robust && h->lbvh_valid ? h->n_rnodes : 0;
     M.rface = h->d_rface;
     M.fbox = h->d_fbox;
     M.gr_start = h->grid.start;
@@ -829,12 +851,9 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     // many faces span too many cells to be listed (every query tests the "big" list), or — without the
     // triangle filter of the cells — when faces touch > 10 cells each at the natural resolution.  With the
     // filter the grid wins also on rough surfaces (noisy icosphere-7, 64M points: 28 against 55 ms).
-    M.ray_lbvh = h->opt_ray_mode == 2 ||
-                         (h->opt_ray_mode == 0 && (h->grid.nbig > 64u || (h->grid.coarsened && !h->opt_grid_tri)))
-                     ? 1
-                     : 0;
+    M.ray_lbvh = lbvh_rule(h) && h->lbvh_valid ? 1 : 0;  // (an option changed since the update: set_option builds it)
     M.gr_o0 = h->grid.gr.o0, M.gr_o1 = h->grid.gr.o1, M.gr_inv0 = h->grid.gr.inv0, M.gr_inv1 = h->grid.gr.inv1;
-    const bool xg = h->robust && h->opt_x_grid && h->grid_x.start;
+    const bool xg = h->robust && h->xgrid_built && h->grid_x.start;
     M.gx_start = xg ? h->grid_x.start : nullptr;
     M.gx_ent = h->grid_x.ent;
     M.gx_big = h->grid_x.big;
@@ -1825,6 +1844,12 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
     else if (!strcmp(key, "ray_mode")) {
         if (v < 0 || v > 2) return fail(SDFHIP_E_INVALID, "ray_mode must be 0 (auto), 1 (grid) or 2 (LBVH)");
         h->opt_ray_mode = v;
+        if (h->robust && h->nf > 0 && h->d_fbox && wants_lbvh(h)) {  // the LBVH is only kept current while something walks it
+            DevGuard g(h->device);
+            if (!g.ok) return fail(SDFHIP_E_HIP, "hipSetDevice(%d) failed", h->device);
+            if (int rc = wait_for_queries(h, h->stream)) return rc;
+            return guarded([&]() -> int { return ensure_lbvh(h); });
+        }
     } else if (!strcmp(key, "grid_per_face")) {
         if (v < 1 || v > 4096) return fail(SDFHIP_E_INVALID, "grid_per_face must be in [1, 4096]");
         h->opt_grid_per_face = v;  // takes effect at the next update / set_raycast_axes
