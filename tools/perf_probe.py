@@ -22,6 +22,7 @@ ap.add_argument("--heavy-budget", type=int, default=0)
 ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--opt", action="append", default=[], help="key=value handle option, set before the rotation is pinned")
 ap.add_argument("--rmin", type=float, default=0.0, help="drop points closer than this to the origin")
+ap.add_argument("--presort", type=int, default=0, help="1: the points already lie in Morton order in memory (the query sort then yields ~identity: coalesced input gather)")
 a = ap.parse_args()
 if a.mesh.startswith("ico"):
     v, f = meshes.icosphere(int(a.mesh[3:]), radius=0.8, noise=a.noise, seed=3)
@@ -49,6 +50,12 @@ else:
     pts = torch.rand((a.n, 3), device=dev, generator=g).mul_(2).sub_(1)
 if a.rmin > 0:
     pts = pts[pts.norm(dim=1) >= a.rmin].contiguous()
+if a.presort:
+    q = ((pts + 1) * 128).clamp_(0, 255).to(torch.int64)
+    def spread(x):
+        x = (x | (x << 16)) & 0x030000FF; x = (x | (x << 8)) & 0x0300F00F; x = (x | (x << 4)) & 0x030C30C3; x = (x | (x << 2)) & 0x09249249; return x
+    key = (spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2])
+    pts = pts[torch.argsort(key)].contiguous(); del q, key
 n = pts.shape[0]
 if a.ray_mode:
     s.set_option("ray_mode", a.ray_mode)

@@ -34,7 +34,7 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.txt"), "w") as fh:
                  f"{float(r['AverageNs'])/1e6:10.4f} {float(r['Percentage']):7.2f}\n")
 acc = collections.defaultdict(float)
 disp = collections.defaultdict(set)
-for f in ("pmc_pf.csv", "pmc_pw.csv", "pmc_pt.csv", "pmc_ps1.csv", "pmc_ps2.csv"):
+for f in ("pmc_pf.csv", "pmc_pw.csv", "pmc_pt.csv", "pmc_ps1.csv", "pmc_ps2.csv", "pmc_psc.csv"):
     p = os.path.join(src, f)
     if not os.path.exists(p):
         continue
@@ -74,6 +74,14 @@ if iv and gui:
     out["valu_issue_util"] = 2.0 * iv / ((gui / 8.0) * 1024.0)
 if thr and act:
     out["valu_lane_util"] = thr / (act * 64.0)
+# scalar data cache (the chunk loads of the walk), per wave (round 1, 4-wide tree: 312 requests per wave)
+rq, hit, mis = per("SQC_DCACHE_REQ"), per("SQC_DCACHE_HITS"), per("SQC_DCACHE_MISSES")
+if rq and per("SQ_WAVES"):
+    # (SQ_WAVES comes from another pass of the same command: the launch is identical)
+    out["sqc_dcache_req_per_wave"] = rq / per("SQ_WAVES")
+    out["sqc_dcache_misses_per_wave"] = None if mis is None else mis / per("SQ_WAVES")
+    out["sqc_dcache_hit_rate"] = None if hit is None else hit / rq
+    out["sqc_tc_data_read_req"] = per("SQC_TC_DATA_READ_REQ")
 if out["read_bytes_low"] is not None and out["write_bytes"] is not None:
     out["traffic_bytes_per_launch"] = out["read_bytes_low"] + out["write_bytes"]
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
