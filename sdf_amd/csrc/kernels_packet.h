@@ -824,13 +824,18 @@ __global__ __launch_bounds__(64 * COOP_WAVES) SDFK_PK_SGPR void k_query_packet_c
     MeshDev M, const float* __restrict__ pts, const uint32_t* __restrict__ perm, int64_t n, int trunc_aabb,
     void* __restrict__ out, unsigned long long* __restrict__ amb_mask, uint32_t* __restrict__ amb_cnt, uint32_t off,
     uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt, CoopDesc CB) {
+    // One block per handed-over packet and NO loop over packets: with a barrier (a fence) or a store ahead of
+    // the walk on any path — the back edge of such a loop — the compiler can no longer prove the tree arrays
+    // unwritten and turns every scalar chunk load of the walk into a vector load (26 global_load_dwordx4 in
+    // place of 9 s_load_dwordx16 in the ISA of the looped version).  The host launches COOP_CAP blocks at
+    // most; those past the count leave at once.
     __shared__ uint32_t sS[COOP_WAVES][7][64];
-    __shared__ uint32_t s_over;
+    __shared__ uint32_t s_over[COOP_WAVES];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t cnt = min(heavy_cnt[1], COOP_CAP);
-    for (uint32_t e = blockIdx.x; e < cnt; e += gridDim.x) {  // block-uniform
-        if (threadIdx.x == 0) s_over = 0u;
-        __syncthreads();
+    const uint32_t e = blockIdx.x;
+    if (e >= cnt) return;  // block-uniform
+    {
         const int64_t i = (int64_t)CB.list[e] * 64 + lane;
         const bool valid = i < n;
         const int64_t ic = valid ? i : n - 1;
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) SDFK_PK_SGPR void k_query_packet_c
         approx_model(M, p, Qf, Ea);
         const bool over = packet_walk<true, true>(M, p.x, p.y, p.z, Qf + Ea, (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A,
                                                   wave, (uint32_t)COOP_WAVES, max(M.coop_budget, M.heavy_budget / 4u));
-        if (over && lane == 0) atomicOr(&s_over, 1u);
+        if (lane == 0) s_over[wave] = over ? 1u : 0u;
         if (wave != 0) {
             sS[wave][0][lane] = __float_as_uint(A.B1), sS[wave][1][lane] = __float_as_uint(A.B2);
             sS[wave][2][lane] = __float_as_uint(A.B3), sS[wave][3][lane] = __float_as_uint(A.B4);
@@ -853,7 +858,9 @@ __global__ __launch_bounds__(64 * COOP_WAVES) SDFK_PK_SGPR void k_query_packet_c
         }
         __syncthreads();
         if (wave == 0) {
-            if (s_over) {
+            uint32_t any_over = 0u;
+            for (int w = 0; w < COOP_WAVES; ++w) any_over |= s_over[w];
+            if (any_over) {
                 packet_to_heavy(valid, i, src, off, amb_mask, amb_cnt, heavy_list, heavy_cnt);
             } else {
                 for (int w = 1; w < COOP_WAVES; ++w) {
@@ -885,7 +892,6 @@ __global__ __launch_bounds__(64 * COOP_WAVES) SDFK_PK_SGPR void k_query_packet_c
                                                   amb_cnt, off, heavy_list, heavy_cnt);
             }
         }
-        __syncthreads();  // LDS is reused by the next packet
     }
 }
 

@@ -1125,7 +1125,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             if (coop) {
                 const int64_t npk = (m + 63) / 64;
                 const CoopDesc CB = {W.coop_list, W.coop_state};
-                k_query_packet_coop<PK, ROBUST><<<(uint32_t)(npk < 1024 ? npk : 1024), 64 * COOP_WAVES, 0, s>>>(
+                k_query_packet_coop<PK, ROBUST><<<(uint32_t)(npk < (int64_t)COOP_CAP ? npk : (int64_t)COOP_CAP), 64 * COOP_WAVES, 0, s>>>(
                     M, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
                     W.fb_list + W.fb_cap, W.fb_count + 2, CB);
                 HIPC(hipMemsetAsync(W.fb_count + 3, 0, sizeof(uint32_t), s));
