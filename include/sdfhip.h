@@ -280,7 +280,7 @@ int sdfhip_host_free(void* p);
  * update: the x+ tie-break ray reads its own column grid over (y', z') instead of walking the LBVH), "column_sort" (0/1: robust
  * contains() sorts its queries by column of the ray-cast frame instead of 3-D Morton order), "coop_budget" (work units after
  * which a packet's walk is continued by eight waves, 0 = never; default 1500), "coop_max" (largest launch, in points, that
- * uses it; default 2^24).  No option changes a result, except "fast_nn" as described. */
+ * uses it; default 2^27 = every launch).  No option changes a result, except "fast_nn" as described. */
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t value);
 
 const char* sdfhip_last_error(void);

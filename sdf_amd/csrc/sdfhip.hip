@@ -186,7 +186,7 @@ struct sdfhip_ctx {
                                    // last call's heavy waves (read back only while profiling)
     int64_t opt_heavy_budget = 0;  // chunks per wave before it gives up; 0 = automatic
     int64_t opt_coop_budget = 1500;  // work units after which a packet goes on in the cooperative kernel; 0 = never
-    int64_t opt_coop_max = 16 << 20;  // launches of more points than this keep their long waves
+    int64_t opt_coop_max = 1 << 27;  // launches of more points than this keep their long waves (default: none does)
     int64_t opt_scan_max = -1;  // n x positions up to which a batch is answered by the exact scan; -1 = automatic
     int64_t opt_packet = 1;
     int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
@@ -1107,9 +1107,10 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             const bool approx = !fast && (h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0);
             h->last_kernel = approx ? SDFHIP_KERNEL_PACKET_APPROX : SDFHIP_KERNEL_PACKET_EXACT;
             // Long walks go on in the cooperative kernel (8 waves per packet); not for ray-only contains().
-            // It is one more serial phase (~0.4 ms): it pays while the launch is short enough for its few long
-            // waves to be the tail (nn 4M 2.68 -> 2.26 ms, 4 x 16M 13.99 -> 13.68 ms), not when they overlap the
-            // rest of a long launch anyway (256^3 grid, 16.8M points in one launch: 3.67 -> 3.78 ms).
+            // It is one more serial phase (~0.3 ms): it pays most while the launch is short enough for its few
+            // long waves to be the tail (nn 4M 2.68 -> 2.09 ms), and since its chunk loads are scalar again
+            // (no loop over packets) also on the longest launches, where fewer packets end in the exact scan
+            // (125M sdf 22.22 -> 21.93 ms, icosphere-7 64M 14.0 -> 13.55 ms).
             const bool coop = approx && M.coop_budget != 0u && W.coop_list && !(ROBUST && KIND == Q_CONTAINS) &&
                               m <= h->opt_coop_max;
             MeshDev Mm = M;  // the main kernel's view: its budget, and in the low bit who takes over beyond it
