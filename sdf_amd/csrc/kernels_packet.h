@@ -302,7 +302,7 @@ __device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y
                                              ApproxState& S) {
     const uint32_t nch = cur & 15u;
     const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
-    const u32x16* C = (const u32x16*)__builtin_assume_aligned(M.kd_pts4 + first, 64);
+    const u32x16* C = (const u32x16*)__builtin_assume_aligned(M.kd_apx4 + first, 64);
     float gm = __builtin_inff();  // (a NaN never enters: fminf keeps the other operand)
 #define SDFK_APX_SLOT(A, O_)                                                               \
     __builtin_fmaf(X2, __uint_as_float(A[O_]),                                             \
@@ -383,9 +383,9 @@ __device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y
 // first L1 node with the saved, nearly final thresholds: groups met again are recognised per lane).
 // budget: work units (chunks evaluated + candidates tested) after which the wave gives up.
 template <bool APPROX, bool CONT>
-__device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy, float qz, float Qe, float cm,
-                                            ExactState& SE, ApproxState& SA, uint32_t part, uint32_t nparts,
-                                            uint32_t budget) {
+__device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy, float qz, float ax, float ay,
+                                            float az, float Qe, float cm, ExactState& SE, ApproxState& SA,
+                                            uint32_t part, uint32_t nparts, uint32_t budget) {
     const uint32_t lane = threadIdx.x & 63u;
     SDFK_COUNT(0, 1);
     if (M.kd_ngroups == 0u) return false;
@@ -402,7 +402,7 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
     // absolute slack of the box tests: 64u x (an upper bound of |c - centre of any box|)
     const float reach = ((fabsf(cx - M.obb_cm[0]) + fabsf(cy - M.obb_cm[1])) + fabsf(cz - M.obb_cm[2])) + (M.obb_rm + rho);
     const float Ew = 3.8146973e-6f * reach;
-    const float X2 = -2.f * qx, Y2 = -2.f * qy, Z2 = -2.f * qz;
+    const float X2 = -2.f * ax, Y2 = -2.f * ay, Z2 = -2.f * az;  // (a: the query in the approximate pass's frame)
     const float c2 = M.amb_c2;
     float rr;  // per lane: sqrt of the lane's threshold, with the slack of the plane test
 #define SDFK_PK_REFRESH()                                                                           \
@@ -634,14 +634,17 @@ __device__ __forceinline__ void packet_to_heavy(bool valid, int64_t i, int64_t s
     if (valid) heavy_list[base + (uint32_t)__popcll(vm & lt)] = off + (uint32_t)src;
 }
 
-// error model of a() for one lane (see "Approximate first pass")
-__device__ __forceinline__ void approx_model(const MeshDev& M, V3 p, float& Qf, float& Ea) {
+// error model of a() for one lane (see "Approximate first pass"); qc: the query in the centred frame
+__device__ __forceinline__ void approx_model(const MeshDev& M, V3 p, V3& qc, float& Qf, float& Ea) {
     const float u = 5.9604645e-8f;  // 2^-24
-    const float Vx = fmaxf(fabsf(M.bb[0]), fabsf(M.bb[3])), Vy = fmaxf(fabsf(M.bb[1]), fabsf(M.bb[4])),
-                Vz = fmaxf(fabsf(M.bb[2]), fabsf(M.bb[5]));
-    const float S = M.vmax2 + 2.f * ((fabsf(p.x) * Vx + fabsf(p.y) * Vy) + fabsf(p.z) * Vz);
-    Qf = (p.x * p.x + p.y * p.y) + p.z * p.z;
-    Ea = u * (5.f * S + 4.f * Qf);
+    const float cx = M.apx_c[0], cy = M.apx_c[1], cz = M.apx_c[2];
+    qc = {p.x - cx, p.y - cy, p.z - cz};
+    // >= |v'_i| of every stored vertex: fl(lo - c) and fl(hi - c) bracket fl(v - c) (rounding is monotone)
+    const float Vx = fmaxf(fabsf(M.bb[0] - cx), fabsf(M.bb[3] - cx)), Vy = fmaxf(fabsf(M.bb[1] - cy), fabsf(M.bb[4] - cy)),
+                Vz = fmaxf(fabsf(M.bb[2] - cz), fabsf(M.bb[5] - cz));
+    const float S = M.vmax2 + 2.f * ((fabsf(qc.x) * Vx + fabsf(qc.y) * Vy) + fabsf(qc.z) * Vz);
+    Qf = (qc.x * qc.x + qc.y * qc.y) + qc.z * qc.z;
+    Ea = u * (M.apx_kS * S + M.apx_kQ * Qf);
 }
 
 // What follows the walk, per lane: the exact second phase (APPROX), the decision whether the walk's answer
@@ -776,11 +779,12 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
     ApproxState A = {INF, INF, INF, INF, H_NONE, H_NONE, H_NONE};
     float Qf = 0.f, Ea = 0.f;
     if (APPROX) {
-        approx_model(M, p, Qf, Ea);
-        pb.bailed = packet_walk<true, false>(M, p.x, p.y, p.z, Qf + Ea, (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A, 0u,
-                                             1u, M.heavy_budget);
+        V3 qc;
+        approx_model(M, p, qc, Qf, Ea);
+        pb.bailed = packet_walk<true, false>(M, p.x, p.y, p.z, qc.x, qc.y, qc.z, Qf + Ea,
+                                             (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A, 0u, 1u, M.heavy_budget);
     } else {
-        pb.bailed = packet_walk<false, false>(M, p.x, p.y, p.z, 0.f, 1.f, SE, A, 0u, 1u, M.heavy_budget);
+        pb.bailed = packet_walk<false, false>(M, p.x, p.y, p.z, p.x, p.y, p.z, 0.f, 1.f, SE, A, 0u, 1u, M.heavy_budget);
         if (SE.b == SE.tieb) SE.s2 = SE.b;  // a settled exact tie is a tie
         pb.b = __uint_as_float(SE.b), pb.s = __uint_as_float(SE.s2), pb.h = SE.h;
     }
@@ -847,8 +851,10 @@ __global__ __launch_bounds__(64 * COOP_WAVES) SDFK_PK_SGPR void k_query_packet_c
                          __uint_as_float(st[192]), st[256],                 st[320],
                          st[384]};
         float Qf, Ea;
-        approx_model(M, p, Qf, Ea);
-        const bool over = packet_walk<true, true>(M, p.x, p.y, p.z, Qf + Ea, (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A,
+        V3 qc;
+        approx_model(M, p, qc, Qf, Ea);
+        const bool over = packet_walk<true, true>(M, p.x, p.y, p.z, qc.x, qc.y, qc.z, Qf + Ea,
+                                                  (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A,
                                                   wave, (uint32_t)COOP_WAVES, max(M.coop_budget, M.heavy_budget / 4u));
         if (lane == 0) s_over[wave] = over ? 1u : 0u;
         if (wave != 0) {

@@ -65,6 +65,21 @@ struct RMat {
     float m[9];
 };
 
+// The approximate pass's own copy of the vertices (tree order), centred on the mesh: v' = fl(v - c) and |v'|^2
+// rounded once from double (the host computes the same numbers for its maximum); sentinels: a() = +inf.
+__global__ void k_apx_fill(const float4* __restrict__ pts4, uint32_t n, float cx, float cy, float cz,
+                           float4* __restrict__ apx4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 P = pts4[i];
+    if (!(P.w < __builtin_inff())) {  // sentinel slot (or a non-finite vertex: its a() must never be a minimum)
+        apx4[i] = make_float4(0.f, 0.f, 0.f, __builtin_inff());
+        return;
+    }
+    const float x = P.x - cx, y = P.y - cy, z = P.z - cz;
+    apx4[i] = make_float4(x, y, z, (float)(((double)x * x + (double)y * y) + (double)z * z));
+}
+
 __global__ void k_face_precompute(const float* __restrict__ verts, const uint32_t* __restrict__ faces,
                                   uint32_t nf, RMat R, int robust, float4* __restrict__ geo,
                                   float4* __restrict__ rface, float* __restrict__ fbox,

@@ -179,6 +179,9 @@ struct sdfhip_ctx {
     int32_t* d_kd_vind = nullptr;
     size_t kd_nodes_cap = 0, kd_pos_cap = 0;
     float4* d_kd_pts4 = nullptr;
+    float4* d_kd_apx4 = nullptr;  // the approximate pass's centred copy (k_apx_fill)
+    float apx_c[3] = {0.f, 0.f, 0.f};
+    bool apx_centred = false;
     float amb_c = 1.f, amb_c2 = 1.f;
     QueryWs ws;            // this handle's own query workspace, grown on demand
     QueryWs* W = &ws;      // the workspace of the running call (the static scratch in the no-alloc entry)
@@ -657,12 +660,12 @@ int build_fast_tree(sdfhip_ctx* h) {
 bool approx_pays(const sdfhip_ctx* h) {
     if (h->nv < 64) return false;
     double V[3], e[3];
-    for (int d = 0; d < 3; ++d) {
-        V[d] = std::fmax(std::fabs((double)h->aabb[d]), std::fabs((double)h->aabb[d + 3]));
+    for (int d = 0; d < 3; ++d) {  // (the pass works in a frame centred on the mesh: V = half extents)
+        V[d] = std::fmax(std::fabs((double)h->aabb[d] - h->apx_c[d]), std::fabs((double)h->aabb[d + 3] - h->apx_c[d]));
         e[d] = (double)h->aabb[d + 3] - (double)h->aabb[d];
     }
     const double S = 3.0 * (V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
-    const double E = 5.9604644775390625e-8 * 5.0 * S;
+    const double E = 5.9604644775390625e-8 * (h->apx_centred ? 7.0 : 5.0) * S;
     const double area = 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
     if (!(area > 0.0) || !std::isfinite(area) || !std::isfinite(S)) return false;
     const double lambda = (double)h->nv / area * 3.141592653589793 * 2.0 * E;
@@ -688,6 +691,21 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     if (int rc = wait_for_queries(h, s)) return rc;  // queries still in flight read what update rewrites
     // mesh AABB (sdf.cpp:36-37; == the kd root box): needed by the device side before the tree
     h->kd.bounds(h->h_verts, h->nv, (int)h->opt_build_threads, h->aabb);
+    {   // Centre of the approximate pass: the fp32 centre of the AABB when the mesh lies off the origin against its
+        // size (then a() is evaluated on fl(v - c), fl(q - c): two more roundings in the error model, constants
+        // (7, 6), but S and Q shrink to the mesh's own scale); the origin otherwise (exact inputs, constants (5, 4)).
+        float c[3], half = 0.f, dist = 0.f;
+        bool finite = true;
+        for (int d = 0; d < 3; ++d) {
+            c[d] = 0.5f * h->aabb[d] + 0.5f * h->aabb[d + 3];
+            finite = finite && std::isfinite(c[d]) && std::isfinite(h->aabb[d + 3] - h->aabb[d]);
+            half = std::fmax(half, 0.5f * (h->aabb[d + 3] - h->aabb[d]));
+            dist = std::fmax(dist, std::fabs(c[d]));
+        }
+        const bool centre = finite && dist > 0.5f * half;
+        for (int d = 0; d < 3; ++d) h->apx_c[d] = centre ? c[d] : 0.f;
+        h->apx_centred = centre;
+    }
     h->approx_ok = approx_pays(h);
     // Packet groups: a slot of the approximate pass costs 3.5 VALU against 10 of the exact walk, so
     // larger groups (fewer box tests and sorted inserts per wave) pay there.  Measured on
@@ -744,9 +762,12 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
             } else {
                 const float* src = h->h_verts + 3 * (size_t)vi;
                 dst[4 * i] = src[0], dst[4 * i + 1] = src[1], dst[4 * i + 2] = src[2];
-                // |v|^2 for the approximate first pass of the packet kernel, rounded once
+                // (w: finite for a vertex, +inf for a sentinel; k_apx_fill tells them apart by it)
                 dst[4 * i + 3] = (float)(((double)src[0] * src[0] + (double)src[1] * src[1]) + (double)src[2] * src[2]);
-                if (dst[4 * i + 3] > vmax2) vmax2 = dst[4 * i + 3];
+                // max |v'|^2 of the approximate pass's centred copy, with k_apx_fill's own arithmetic
+                const float x = src[0] - h->apx_c[0], y = src[1] - h->apx_c[1], z = src[2] - h->apx_c[2];
+                const float w = (float)(((double)x * x + (double)y * y) + (double)z * z);
+                if (w > vmax2) vmax2 = w;
             }
         }
         return vmax2;
@@ -768,6 +789,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     if (nalloc > h->kd_pos_cap) {
         if (int rc = dalloc(&h->d_kd_pts4, nalloc)) return rc;
         if (int rc = dalloc(&h->d_kd_vind, nalloc)) return rc;
+        if (int rc = dalloc(&h->d_kd_apx4, nalloc)) return rc;
         h->kd_pos_cap = nalloc;
     }
     {   // ambiguity factor of the packet pass: c = (1 + w_th + 4u) rounded up, w_th = u(3.02 D + 11.2)
@@ -785,6 +807,8 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
                             hipMemcpyHostToDevice, s));
     HIPC(hipMemcpyAsync(h->d_kd_pts4, h->perm_pts4.data(), sizeof(float) * 4 * nalloc,
                         hipMemcpyHostToDevice, s));
+    k_apx_fill<<<(uint32_t)((nalloc + 255) / 256), 256, 0, s>>>(h->d_kd_pts4, (uint32_t)nalloc, h->apx_c[0], h->apx_c[1],
+                                                               h->apx_c[2], h->d_kd_apx4);
     if (!h->kd.nodes.empty()) {
         HIPC(hipMemcpyAsync(h->d_kd_pn, h->kd.nodes.data(), sizeof(sdfk::KdNodeH) * h->kd.nodes.size(),
                             hipMemcpyHostToDevice, s));
@@ -825,6 +849,9 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.kd_root = h->fast_active ? KD_LEAF : h->kd.root_ref;
     for (int d = 0; d < 6; ++d) M.bb[d] = h->aabb[d];
     M.kd_pts4 = h->d_kd_pts4;
+    M.kd_apx4 = h->d_kd_apx4;
+    for (int d = 0; d < 3; ++d) M.apx_c[d] = h->apx_c[d];
+    M.apx_kS = h->apx_centred ? 7.f : 5.f, M.apx_kQ = h->apx_centred ? 6.f : 4.f;
     M.kd_npos = h->fast_active ? (uint32_t)(FAST_GROUP * ((h->nv + FAST_GROUP - 1) / FAST_GROUP))
                                : (uint32_t)h->kd.pos_vert.size();
     // a wave may walk 1/8 of the tree (4 positions per chunk) before it hands its queries over
@@ -1538,7 +1565,7 @@ void sdfhip_destroy(sdfhip_t* h) {
                     h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
-                    h->topo.depthI, h->ws.qkeys, h->ws.qperm, h->ws.qbounds, h->d_gstack, h->d_kd_pts4,
+                    h->topo.depthI, h->ws.qkeys, h->ws.qperm, h->ws.qbounds, h->d_gstack, h->d_kd_pts4, h->d_kd_apx4,
                     h->ws.fb_list, h->ws.fb_count, h->ws.coop_list, h->ws.coop_state, h->ws.amb_mask, h->ws.amb_cnt, h->ws.amb_s1, h->ws.amb_s2,
                     h->d_vkeys, h->d_vidx};
     for (void* p : ptrs)

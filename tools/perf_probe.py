@@ -22,6 +22,7 @@ ap.add_argument("--heavy-budget", type=int, default=0)
 ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--opt", action="append", default=[], help="key=value handle option, set before the rotation is pinned")
 ap.add_argument("--rmin", type=float, default=0.0, help="drop points closer than this to the origin")
+ap.add_argument("--offset", type=float, default=0.0, help="translate mesh and points by (offset, -offset/2, offset/4)")
 ap.add_argument("--presort", type=int, default=0, help="1: the points already lie in Morton order in memory (the query sort then yields ~identity: coalesced input gather)")
 a = ap.parse_args()
 if a.mesh.startswith("ico"):
@@ -32,6 +33,9 @@ elif a.mesh == "teapot":
     v, f = g["verts"], g["faces"]
 else:
     v, f = meshes.torus(a.res, a.res)
+if a.offset:
+    import numpy as _np2
+    v = (v + _np2.array([a.offset, -a.offset / 2, a.offset / 4], _np2.float32)).astype(_np2.float32)
 print("mesh", a.mesh, v.shape, f.shape)
 s = sdf_amd.SDF(v, f, robust=bool(a.robust))
 if a.group:
@@ -48,6 +52,8 @@ if a.grid:
 else:
     g = torch.Generator(device=dev).manual_seed(7)
     pts = torch.rand((a.n, 3), device=dev, generator=g).mul_(2).sub_(1)
+if a.offset:
+    pts = (pts + torch.tensor([a.offset, -a.offset / 2, a.offset / 4], device=dev)).contiguous()
 if a.rmin > 0:
     pts = pts[pts.norm(dim=1) >= a.rmin].contiguous()
 if a.presort:
