@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""RCCL smoke on a one-GPU box: world size 1 over backend nccl, through the same calls bench.py / sdf_amd.distributed
+make with N > 1 (init with device_id, broadcast_mesh on device tensors, barrier, all_reduce MAX of the step time)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
+import numpy as np, torch, torch.distributed as dist
+from sdf_amd import meshes
+from sdf_amd.distributed import broadcast_mesh, ShardedSDF
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)
+v, f = meshes.torus(60, 60); R = meshes.random_rotation(3)
+v2, f2, R2 = broadcast_mesh(v, f, R, src=0, device=dev)
+assert (v2 == v).all() and (f2 == f).all() and (R2 == R).all()
+t = torch.tensor([1.25], device=dev, dtype=torch.float64)
+dist.barrier(); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t) == 1.25
+s = ShardedSDF(v, f, robust=True)
+pts = np.random.default_rng(0).uniform(-1, 1, (10000, 3)).astype(np.float32)
+lo, hi, d = s.sdf_local(pts)
+full = s.gather(pts.shape[0], lo, hi, d, torch.float32)
+assert (full.view(np.uint32) == np.asarray(d).view(np.uint32)).all()
+s.update((v * 1.01).astype(np.float32), None)
+_, _, d2 = s.sdf_local(pts)
+print("nccl world-size-1 ok", full.shape, float(np.abs(np.asarray(d2) - np.asarray(d)).max()))
+dist.destroy_process_group()
