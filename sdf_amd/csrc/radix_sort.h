@@ -7,7 +7,7 @@
 //   k_rs_hist   : per-tile digit histogram (LDS atomics) -> hist[digit][tile]
 //   scan        : exclusive scan of hist (digit-major), hierarchical
 //   k_rs_scatter: per 64-key wave chunk, ballot "match" masks give each key its stable rank
-//                 among equal digits; chunk bases are scanned in LDS per digit
+//                 among equal digits; chunk bases from per-wave running digit counts in LDS
 // =========================================================================================
 constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 12;
@@ -96,20 +96,20 @@ static int exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* s1, uint32_t
     return 0;
 }
 
-// Stable scatter of one tile.  Ranks come from per-64-key-chunk ballot "match" masks; the tile
-// is first permuted into digit order inside LDS so that consecutive lanes then write
-// consecutive global addresses (runs of tile/256 elements per digit instead of single keys).
+// Stable scatter of one tile.  Wave w owns the tile's elements [w * 768, (w + 1) * 768) as 12 chunks of 64
+// consecutive keys.  Ranks: a ballot "match" gives each key its rank among the equal digits of its chunk, and a
+// per-wave running count per digit (LDS, [wave][digit]; a wave's chunks go through it in order, so no atomics and
+// no zero-filled chunk x digit matrix as in the first version: 230 -> 110 LDS operations per thread) gives the
+// chunk's base.  A scan over the 4 x 256 wave totals then places every (digit, wave) run, the tile is permuted
+// into digit order inside LDS, and consecutive lanes write consecutive global addresses (runs of tile/256
+// elements per digit instead of single keys).
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift,
     const uint32_t* __restrict__ hist, uint32_t ntiles, int vals_iota) {
-    // 24 KB used twice (6 blocks per CU instead of 3): first the per (chunk, digit) counts ->
-    // offsets, then — once every thread holds its slots in registers — the tile in digit order
-    __shared__ uint32_t lds_u[2 * RS_TILE];
-    static_assert(sizeof(uint16_t) * RS_CHUNKS * 256 <= sizeof(uint32_t) * 2 * RS_TILE, "cnt fits the tile buffers");
-    uint16_t* cnt = (uint16_t*)lds_u;
-    uint32_t* skey = lds_u;
-    uint32_t* sval = lds_u + RS_TILE;
+    __shared__ uint32_t skey[RS_TILE];
+    __shared__ uint32_t sval[RS_TILE];
+    __shared__ uint32_t wcnt[4][256];          // per wave: running count of each digit, then the run's first slot
     __shared__ uint32_t bstart[256];           // first local slot of each digit
     __shared__ uint32_t gbase[256];            // global base of each digit for this tile
     __shared__ uint32_t wsum[4];
@@ -119,35 +119,47 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     // as whole lines.  (grid = 8 * ceil(ntiles / 8) blocks.)
     const uint32_t tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (tile >= ntiles) return;  // block-uniform
-    for (int k = threadIdx.x; k < RS_CHUNKS * 256; k += RS_THREADS) cnt[k] = 0;
-    __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wcnt[k][threadIdx.x] = 0;
     const uint32_t base = tile * RS_TILE;
+    const uint32_t wbase = base + (uint32_t)w * (RS_ITEMS * 64);
     uint32_t key[RS_ITEMS], val[RS_ITEMS];
-    uint16_t rank[RS_ITEMS];
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int k = 0; k < RS_ITEMS; ++k) {
-        const int chunk = k * 4 + w;  // ascending key index
-        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {  // all loads in flight before the first LDS round trip
+        const uint32_t i = wbase + k * 64 + lane;
         const bool valid = i < n;
         key[k] = valid ? keys_in[i] : 0xFFFFFFFFu;
         val[k] = valid ? (vals_iota ? i : vals_in[i]) : 0u;
+    }
+    __syncthreads();  // wcnt is zero
+    uint16_t rank[RS_ITEMS];
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const uint32_t i = wbase + k * 64 + lane;
+        const bool valid = i < n;
         const uint32_t dg = (key[k] >> shift) & 255u;
         unsigned long long m = __ballot(valid);
+#pragma unroll
         for (int b = 0; b < 8; ++b) {
             const unsigned long long bl = __ballot((dg >> b) & 1u);
             m &= ((dg >> b) & 1u) ? bl : ~bl;
         }
-        rank[k] = (uint16_t)__popcll(m & lt);
-        if (valid && rank[k] == 0) cnt[chunk * 256 + dg] = (uint16_t)__popcll(m);
+        const uint32_t r = (uint32_t)__popcll(m & lt);
+        const uint32_t before = wcnt[w][dg];  // (this wave's earlier chunks; its own writes, in program order)
+        rank[k] = (uint16_t)(before + r);
+        if (valid && r == 0) wcnt[w][dg] = before + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();  // (the next chunk reads what other lanes of this wave wrote)
     }
     __syncthreads();
-    {   // thread = digit: offsets of its chunks, then a block scan of the digit totals
+    {   // thread = digit: the four wave totals -> first slot of each (digit, wave) run; block scan of the digit totals
         const uint32_t dg = threadIdx.x;
         uint32_t run = 0;
-        for (int c = 0; c < RS_CHUNKS; ++c) {
-            const uint32_t t = cnt[c * 256 + dg];
-            cnt[c * 256 + dg] = (uint16_t)run;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t t = wcnt[k][dg];
+            wcnt[k][dg] = run;
             run += t;
         }
         uint32_t x = run;
@@ -163,21 +175,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
         gbase[dg] = hist[dg * ntiles + tile];
     }
     __syncthreads();
-    for (int k = 0; k < RS_ITEMS; ++k) {  // rank[] becomes the slot in the tile
-        const int chunk = k * 4 + w;
-        const uint32_t dg = (key[k] >> shift) & 255u;
-        rank[k] = (uint16_t)(bstart[dg] + cnt[chunk * 256 + dg] + rank[k]);
-    }
-    __syncthreads();  // cnt is dead: its memory takes the tile
+#pragma unroll
     for (int k = 0; k < RS_ITEMS; ++k) {
-        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+        const uint32_t i = wbase + k * 64 + lane;
         if (i < n) {
-            skey[rank[k]] = key[k];
-            sval[rank[k]] = val[k];
+            const uint32_t dg = (key[k] >> shift) & 255u;
+            const uint32_t slot = bstart[dg] + wcnt[w][dg] + rank[k];
+            skey[slot] = key[k];
+            sval[slot] = val[k];
         }
     }
     __syncthreads();
     const uint32_t tile_n = (n - base) < (uint32_t)RS_TILE ? (n - base) : (uint32_t)RS_TILE;
+#pragma unroll
     for (int k = 0; k < RS_ITEMS; ++k) {
         const uint32_t slot = k * RS_THREADS + threadIdx.x;
         if (slot < tile_n) {
