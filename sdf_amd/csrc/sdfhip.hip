@@ -242,6 +242,11 @@ struct sdfhip_ctx {
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     float* d_stage_in[2] = {nullptr, nullptr};
+    // page-locked bounce buffers for pageable caller memory (see BounceCopy): two per direction
+    unsigned char* pin_up[2] = {nullptr, nullptr};
+    unsigned char* pin_dn[2] = {nullptr, nullptr};
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_dn[2] = {nullptr, nullptr};
+    std::unique_ptr<sdfk::KdTeam> team_up, team_dn;  // 3 helpers each: one thread copies 32 GB/s, four 62 GB/s
     void* d_stage_out[2] = {nullptr, nullptr};
     int64_t stage_cap = 0;     // points per staging slot
     int64_t opt_host_chunk = 0;  // 0 = automatic
@@ -1216,6 +1221,81 @@ int run_query(sdfhip_ctx* h, int kind, const float* d_pts, int64_t n, int trunc,
 // so that the PCIe transfers of pageable caller memory (blocking for the host, asynchronous
 // for the GPU) overlap the kernels.  Chunks stay large (see the schedule in run_query_host): the
 // packet pass is faster on dense Morton-sorted batches and every chunk pays the serial phases once.
+// Pageable caller memory.  hipMemcpyAsync stages such copies itself, at 31 GB/s host-to-device and 18 GB/s
+// device-to-host on the target box, blocking the caller; a plain memcpy into page-locked memory runs at
+// 60+ GB/s on one thread and the DMA from there at 57 GB/s, so the two are pipelined by hand: pieces of
+// BOUNCE_BYTES through two page-locked buffers per direction (copy piece i + 1 while piece i is on the bus).
+constexpr size_t BOUNCE_BYTES = (size_t)8 << 20;
+constexpr int BOUNCE_THREADS = 4;
+bool is_pageable(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // (an unregistered pointer is reported as an error by some versions)
+        return true;
+    }
+    return a.type == hipMemoryTypeUnregistered;
+}
+int ensure_bounce(sdfhip_ctx* h) {
+    for (int k = 0; k < 2; ++k) {
+        if (!h->pin_up[k] && hipHostMalloc((void**)&h->pin_up[k], BOUNCE_BYTES, hipHostMallocDefault) != hipSuccess)
+            return fail(SDFHIP_E_NOMEM, "hipHostMalloc failed for the bounce buffers");
+        if (!h->pin_dn[k] && hipHostMalloc((void**)&h->pin_dn[k], BOUNCE_BYTES, hipHostMallocDefault) != hipSuccess)
+            return fail(SDFHIP_E_NOMEM, "hipHostMalloc failed for the bounce buffers");
+        if (!h->ev_up[k]) HIPC(hipEventCreateWithFlags(&h->ev_up[k], hipEventDisableTiming));
+        if (!h->ev_dn[k]) HIPC(hipEventCreateWithFlags(&h->ev_dn[k], hipEventDisableTiming));
+    }
+    if (!h->team_up) h->team_up.reset(new sdfk::KdTeam(BOUNCE_THREADS - 1));
+    if (!h->team_dn) h->team_dn.reset(new sdfk::KdTeam(BOUNCE_THREADS - 1));
+    return 0;
+}
+// memcpy by the caller and the team's helpers, in 64-byte aligned slices
+void team_memcpy(sdfk::KdTeam& team, void* dst, const void* src, size_t len) {
+    const size_t per = ((len + BOUNCE_THREADS - 1) / BOUNCE_THREADS + 63) & ~(size_t)63;
+    team.run(BOUNCE_THREADS, [&](int t) {
+        const size_t lo = (size_t)t * per;
+        if (lo < len) std::memcpy((char*)dst + lo, (const char*)src + lo, len - lo < per ? len - lo : per);
+    });
+}
+// host -> device on `s`; returns once the last piece is enqueued (the source may be reused when it returns:
+// every byte has left it).  One caller at a time per direction (the handle's mutex / the download thread).
+hipError_t bounce_h2d(sdfhip_ctx* h, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    hipError_t e = hipSuccess;
+    sdfk::KdTeam::Session awake(*h->team_up);  // (the helpers spin between the pieces of this copy only)
+    for (size_t off = 0, i = 0; off < bytes && e == hipSuccess; off += BOUNCE_BYTES, ++i) {
+        const int b = (int)(i & 1);
+        const size_t len = bytes - off < BOUNCE_BYTES ? bytes - off : BOUNCE_BYTES;
+        if (i >= 2) e = hipEventSynchronize(h->ev_up[b]);  // the DMA that last read this buffer
+        if (e != hipSuccess) break;
+        team_memcpy(*h->team_up, h->pin_up[b], (const char*)src + off, len);
+        e = hipMemcpyAsync((char*)dst + off, h->pin_up[b], len, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipEventRecord(h->ev_up[b], s);
+    }
+    // the buffers are reused by the next call: wait for the last two DMAs (the bus time, not more)
+    for (int b = 0; b < 2 && e == hipSuccess; ++b)
+        if (bytes > (size_t)b * BOUNCE_BYTES) e = hipEventSynchronize(h->ev_up[b]);
+    return e;
+}
+// device -> host on `s`, complete when it returns
+hipError_t bounce_d2h(sdfhip_ctx* h, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    hipError_t e = hipSuccess;
+    sdfk::KdTeam::Session awake(*h->team_dn);
+    const size_t np = (bytes + BOUNCE_BYTES - 1) / BOUNCE_BYTES;
+    auto len_of = [&](size_t i) { return bytes - i * BOUNCE_BYTES < BOUNCE_BYTES ? bytes - i * BOUNCE_BYTES : BOUNCE_BYTES; };
+    for (size_t i = 0; i <= np && e == hipSuccess; ++i) {
+        if (i < np) {  // piece i on the bus ...
+            const int b = (int)(i & 1);
+            e = hipMemcpyAsync(h->pin_dn[b], (const char*)src + i * BOUNCE_BYTES, len_of(i), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipEventRecord(h->ev_dn[b], s);
+        }
+        if (i >= 1 && e == hipSuccess) {  // ... while piece i - 1 goes home
+            const int b = (int)((i - 1) & 1);
+            e = hipEventSynchronize(h->ev_dn[b]);
+            if (e == hipSuccess) team_memcpy(*h->team_dn, (char*)dst + (i - 1) * BOUNCE_BYTES, h->pin_dn[b], len_of(i - 1));
+        }
+    }
+    return e;
+}
+
 int ensure_host_staging(sdfhip_ctx* h, int64_t cap) {
     if (!h->s_in) HIPC(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
     if (!h->s_out) HIPC(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
@@ -1272,14 +1352,25 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
     for (int64_t c = 0; c < nchunks; ++c) cap = std::max(cap, start[c + 1] - start[c]);
     if (int rc = ensure_host_staging(h, cap)) return rc;
     if (int rc = wait_for_queries(h, h->stream)) return rc;  // (this call ends synchronised: nothing to mark)
+    // pageable arrays of a megabyte or more go through the page-locked bounce buffers (BounceCopy above)
+    const bool pg_in = sizeof(float) * 3 * (size_t)n >= ((size_t)1 << 20) && is_pageable(pts);
+    const bool pg_out = osz * (size_t)n >= ((size_t)1 << 20) && is_pageable(out);
+    if (pg_in || pg_out)
+        if (int rc = ensure_bounce(h)) return rc;
     if (nchunks == 1) {  // nothing to overlap: one stream, no helper thread (latency of small calls)
         hipStream_t s = h->stream;
-        HIPC(hipMemcpyAsync(h->d_stage_in[0], pts, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+        if (pg_in)
+            HIPC(bounce_h2d(h, h->d_stage_in[0], pts, sizeof(float) * 3 * (size_t)n, s));
+        else
+            HIPC(hipMemcpyAsync(h->d_stage_in[0], pts, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
         if (int rc1 = run_query(h, kind, h->d_stage_in[0], n, trunc, h->d_stage_out[0], s)) {
             (void)hipStreamSynchronize(s);
             return rc1;
         }
-        HIPC(hipMemcpyAsync(out, h->d_stage_out[0], osz * (size_t)n, hipMemcpyDeviceToHost, s));
+        if (pg_out)
+            HIPC(bounce_d2h(h, out, h->d_stage_out[0], osz * (size_t)n, s));
+        else
+            HIPC(hipMemcpyAsync(out, h->d_stage_out[0], osz * (size_t)n, hipMemcpyDeviceToHost, s));
         HIPC(hipStreamSynchronize(s));
         return 0;
     }
@@ -1288,8 +1379,11 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
     hipError_t e = hipSuccess;
     auto upload = [&](int64_t c) {
         const int k = (int)(c & 1);
-        e = hipMemcpyAsync(h->d_stage_in[k], pts + 3 * start[c], sizeof(float) * 3 * (size_t)span(c),
-                           hipMemcpyHostToDevice, h->s_in);
+        if (pg_in)
+            e = bounce_h2d(h, h->d_stage_in[k], pts + 3 * start[c], sizeof(float) * 3 * (size_t)span(c), h->s_in);
+        else
+            e = hipMemcpyAsync(h->d_stage_in[k], pts + 3 * start[c], sizeof(float) * 3 * (size_t)span(c),
+                               hipMemcpyHostToDevice, h->s_in);
         if (e == hipSuccess) e = hipEventRecord(h->ev_in[k], h->s_in);
     };
     auto launch = [&](int64_t c) {
@@ -1322,8 +1416,10 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
             const int k = (int)(c & 1);
             hipError_t ed = hipStreamWaitEvent(h->s_out, h->ev_done[k], 0);
             if (ed == hipSuccess)
-                ed = hipMemcpyAsync((char*)out + osz * (size_t)start[c], h->d_stage_out[k],
-                                    osz * (size_t)span(c), hipMemcpyDeviceToHost, h->s_out);
+                ed = pg_out ? bounce_d2h(h, (char*)out + osz * (size_t)start[c], h->d_stage_out[k],
+                                         osz * (size_t)span(c), h->s_out)
+                            : hipMemcpyAsync((char*)out + osz * (size_t)start[c], h->d_stage_out[k],
+                                             osz * (size_t)span(c), hipMemcpyDeviceToHost, h->s_out);
             if (ed == hipSuccess) ed = hipStreamSynchronize(h->s_out);
             std::lock_guard<std::mutex> l(mx);
             if (ed != hipSuccess) e_dl = ed;
@@ -1572,6 +1668,12 @@ void sdfhip_destroy(sdfhip_t* h) {
         if (p) (void)hipFree(p);
     h->ws.sorter.release();
     if (h->h_counts) (void)hipHostFree(h->h_counts);
+    for (int k = 0; k < 2; ++k) {
+        if (h->pin_up[k]) (void)hipHostFree(h->pin_up[k]);
+        if (h->pin_dn[k]) (void)hipHostFree(h->pin_dn[k]);
+        if (h->ev_up[k]) (void)hipEventDestroy(h->ev_up[k]);
+        if (h->ev_dn[k]) (void)hipEventDestroy(h->ev_dn[k]);
+    }
     h->grid.release();
     h->grid_x.release();
     for (int k = 0; k < 2; ++k) {
