@@ -1377,8 +1377,13 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
     auto span = [&](int64_t c) { return start[c + 1] - start[c]; };
     int rc = 0;
     hipError_t e = hipSuccess;
+    static const bool dbg = std::getenv("SDFHIP_DEBUG_HOST") != nullptr;
+    const auto T0 = std::chrono::steady_clock::now();
+    auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count(); };
     auto upload = [&](int64_t c) {
         const int k = (int)(c & 1);
+        const double t0 = now_ms();
+        struct Done { bool on; int64_t c; double t0; decltype(now_ms)& f; ~Done() { if (on) std::fprintf(stderr, "[host] upload %lld: %.2f .. %.2f\n", (long long)c, t0, f()); } } done{dbg, c, t0, now_ms};
         if (pg_in)
             e = bounce_h2d(h, h->d_stage_in[k], pts + 3 * start[c], sizeof(float) * 3 * (size_t)span(c), h->s_in);
         else
@@ -1414,13 +1419,19 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
                 if (launched <= c) return;
             }
             const int k = (int)(c & 1);
-            hipError_t ed = hipStreamWaitEvent(h->s_out, h->ev_done[k], 0);
+            // The wait is on the host, not a hipStreamWaitEvent on s_out: copies queued behind a pending
+            // stream wait made the runtime run the uploads on s_in at half speed while kernels were in flight
+            // (32M pageable points: 21 ms instead of 14 ms per call; tools/numpy_call_probe.py).
+            hipError_t ed = hipEventSynchronize(h->ev_done[k]);
+            const double tdw = now_ms();
             if (ed == hipSuccess)
                 ed = pg_out ? bounce_d2h(h, (char*)out + osz * (size_t)start[c], h->d_stage_out[k],
                                          osz * (size_t)span(c), h->s_out)
                             : hipMemcpyAsync((char*)out + osz * (size_t)start[c], h->d_stage_out[k],
                                              osz * (size_t)span(c), hipMemcpyDeviceToHost, h->s_out);
+            const double td0 = now_ms();
             if (ed == hipSuccess) ed = hipStreamSynchronize(h->s_out);
+            if (dbg) std::fprintf(stderr, "[host] download %lld: start %.2f issued %.2f done %.2f\n", (long long)c, tdw, td0, now_ms());
             std::lock_guard<std::mutex> l(mx);
             if (ed != hipSuccess) e_dl = ed;
             downloaded = c + 1;  // slot k is free again
