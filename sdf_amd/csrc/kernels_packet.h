@@ -116,7 +116,8 @@ typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
 #ifdef SDFK_STATS
 // tuning build only (make stats): per-wave work counters of the packet pass
-__device__ unsigned long long g_pk_stats[8];  // waves, wide tests, groups, chunks, tie redos, candidates, near ties, deferred
+__device__ unsigned long long g_pk_stats[12];  // waves, wide tests, groups, chunks, tie redos, candidates, near ties, deferred,
+                                               // leaf-box passes, of those failing the path walk (must be 0), path walks
 #define SDFK_COUNT(K, V) if ((threadIdx.x & 63) == 0) atomicAdd(&g_pk_stats[K], (unsigned long long)(V))
 #else
 #define SDFK_COUNT(K, V)
@@ -618,6 +619,33 @@ __device__ __forceinline__ float kd_path_max_bound(const MeshDev& M, float qx, f
     return worst_bound;
 }
 
+// The path check proper: true when none of nanoflann's tests on the way to `pos` can fail while `worst`
+// is >= s.  First a sufficient test without the walk.  Every plane on the path separates the query from
+// the leaf of `pos` in its dimension (far descents only; lowside <=> val < divhigh, else val >= divlow, by
+// monotone rounding), and so does the root box's side where the query lies outside it: with t_d = the
+// distance from q_d to the leaf's tight interval, each dists[d] on the path is at most t_d^2 in exact
+// arithmetic, exactly as for a vertex of the leaf, and the bound of the window test carries over with the
+// box's nearest point in the vertex's place: m2 <= BD (1 + w_th), BD = sum t_d^2.  box_lb evaluates BD
+// within 5.01u, the product rounds within u: bd * c^2 <= s (c^2 = amb_c2 >= 1 + w_th + 7u) implies every
+// m2 <= s.  bd == 0: the query is inside the box, every cut on the path is exactly 0.  Tiny bd: relative
+// bounds are void, walk.  The box is nearer than the vertex by about (leaf size) x (distance), the window
+// is 1e-5 relative: the walk (20 dependent loads, ~450 VALU of the wave for 2 lanes in 64) is rare.
+__device__ __forceinline__ bool kd_path_clear(const MeshDev& M, float qx, float qy, float qz, int pos, float s) {
+    const float4 A = M.kd_lbox[2 * (size_t)pos], B = M.kd_lbox[2 * (size_t)pos + 1];
+    const float bd = box_lb(qx, qy, qz, A.x, A.y, A.z, A.w, B.x, B.y);
+    const bool quick = bd == 0.f || (bd >= 1e-30f && bd * M.amb_c2 <= s);
+#ifdef SDFK_STATS
+    const bool full = kd_path_max_bound(M, qx, qy, qz, pos) <= s;
+    if (quick) atomicAdd(&g_pk_stats[8], 1ull);
+    if (quick && !full) atomicAdd(&g_pk_stats[9], 1ull);
+    if (!quick) atomicAdd(&g_pk_stats[10], 1ull);
+    return full;
+#else
+    if (quick) return true;
+    return kd_path_max_bound(M, qx, qy, qz, pos) <= s;
+#endif
+}
+
 // every valid query of this wave goes to the heavy list (absolute indices); wave-uniform
 __device__ __forceinline__ void packet_to_heavy(bool valid, int64_t i, int64_t src, uint32_t off,
                                                 unsigned long long* __restrict__ amb_mask, uint32_t* __restrict__ amb_cnt,
@@ -700,8 +728,7 @@ __device__ __forceinline__ void packet_finish(const MeshDev& M, V3 p, bool valid
             atomicAdd(&g_pk_stats[6], 1ull);
 #endif
             if (pos >= 0 && pb.b < FLT_MAX) {
-                const float mb = kd_path_max_bound(M, p.x, p.y, p.z, pos);
-                amb = !(mb <= pb.s);
+                amb = !kd_path_clear(M, p.x, p.y, p.z, pos, pb.s);
             }
         }
         if (pos < 0) amb = true;
@@ -1069,7 +1096,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_query_heavy(MeshDev M, const flo
         if (!M.fast) {
             if (!(sf > bf * M.amb_c) || !(bf >= 1e-30f)) {
                 amb = true;
-                if (pos >= 0 && bf < FLT_MAX) amb = !(kd_path_max_bound(M, mp.x, mp.y, mp.z, pos) <= sf);
+                if (pos >= 0 && bf < FLT_MAX) amb = !kd_path_clear(M, mp.x, mp.y, mp.z, pos, sf);
             }
             if (pos < 0) amb = true;
         }

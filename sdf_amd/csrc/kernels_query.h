@@ -29,6 +29,7 @@ struct MeshDev {
     float bb[6];  // mesh AABB == kd root bbox
     // packet traversal extras: vertices padded to 16 B, ambiguity factors c = 1 + W and ~c^2
     const float4* kd_pts4;
+    const float4* kd_lbox;  // per tree position, 32 B: the tight box of its kd leaf {lo.xyz, hi.x}, {hi.yz, 0, 0} (kd_path_clear)
     uint32_t kd_npos;       // padded tree positions (sentinel slots included)
     uint32_t heavy_budget;  // packet pass: a wave that has evaluated more chunks than this gives up
     uint32_t coop_budget;   // ... and hands its packet to the cooperative kernel past this many (approximate walk)

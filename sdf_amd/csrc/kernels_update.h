@@ -67,6 +67,41 @@ struct RMat {
 
 // The approximate pass's own copy of the vertices (tree order), centred on the mesh: v' = fl(v - c) and |v'|^2
 // rounded once from double (the host computes the same numbers for its maximum); sentinels: a() = +inf.
+// kd_lbox: every tree position gets the tight box of its kd leaf, taken from the parent node's child box
+// (what nanoflann's divideTree returns for a leaf: the extent of its points).  One thread per node; a tree
+// that is one leaf (no nodes) takes the root box.
+__global__ void k_leaf_boxes(const float4* __restrict__ pn, uint32_t nnodes, uint32_t root, float b0, float b1, float b2,
+                             float b3, float b4, float b5, float4* __restrict__ lbox) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nnodes == 0) {
+        if (i == 0 && (root & sdfk::KD_LEAF_BIT)) {
+            const uint32_t left = (root & sdfk::KD_REF_MASK) >> 4, cnt = root & 15u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                lbox[2 * (size_t)(left + k)] = make_float4(b0, b1, b2, b3);
+                lbox[2 * (size_t)(left + k) + 1] = make_float4(b4, b5, 0.f, 0.f);
+            }
+        }
+        return;
+    }
+    if (i >= nnodes) return;
+    const float4 bA = pn[4 * (size_t)i], bB = pn[4 * (size_t)i + 1], bC = pn[4 * (size_t)i + 2], nf = pn[4 * (size_t)i + 3];
+    const uint32_t r1 = __float_as_uint(nf.z) & ~(3u << sdfk::KD_FEAT_SHIFT), r2 = __float_as_uint(nf.w);
+    if (r1 & sdfk::KD_LEAF_BIT) {
+        const uint32_t left = (r1 & sdfk::KD_REF_MASK) >> 4, cnt = r1 & 15u;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            lbox[2 * (size_t)(left + k)] = make_float4(bA.x, bA.y, bA.z, bA.w);
+            lbox[2 * (size_t)(left + k) + 1] = make_float4(bB.x, bB.y, 0.f, 0.f);
+        }
+    }
+    if (r2 & sdfk::KD_LEAF_BIT) {
+        const uint32_t left = (r2 & sdfk::KD_REF_MASK) >> 4, cnt = r2 & 15u;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            lbox[2 * (size_t)(left + k)] = make_float4(bB.z, bB.w, bC.x, bC.y);
+            lbox[2 * (size_t)(left + k) + 1] = make_float4(bC.z, bC.w, 0.f, 0.f);
+        }
+    }
+}
+
 __global__ void k_apx_fill(const float4* __restrict__ pts4, uint32_t n, float cx, float cy, float cz,
                            float4* __restrict__ apx4) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -180,6 +180,8 @@ struct sdfhip_ctx {
     size_t kd_nodes_cap = 0, kd_pos_cap = 0;
     float4* d_kd_pts4 = nullptr;
     float4* d_kd_apx4 = nullptr;  // the approximate pass's centred copy (k_apx_fill)
+    float4* d_kd_lbox = nullptr;  // per position: its leaf's tight box (k_leaf_boxes, kd_path_clear)
+    size_t kd_lbox_cap = 0;
     float apx_c[3] = {0.f, 0.f, 0.f};
     bool apx_centred = false;
     float amb_c = 1.f, amb_c2 = 1.f;
@@ -797,6 +799,10 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
         if (int rc = dalloc(&h->d_kd_apx4, nalloc)) return rc;
         h->kd_pos_cap = nalloc;
     }
+    if (nalloc > h->kd_lbox_cap) {  // (the GPU-built tree of fast_nn has none: a capacity of its own)
+        if (int rc = dalloc(&h->d_kd_lbox, 2 * nalloc)) return rc;
+        h->kd_lbox_cap = nalloc;
+    }
     {   // ambiguity factor of the packet pass: c = (1 + w_th + 4u) rounded up, w_th = u(3.02 D + 11.2)
         const double u = 5.9604644775390625e-8;
         const double w = u * (3.02 * (double)(h->kd.depth > 0 ? h->kd.depth : 1) + 11.2) + 4.0 * u;
@@ -819,6 +825,11 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
                             hipMemcpyHostToDevice, s));
         HIPC(hipMemcpyAsync(h->d_kd_split, h->kd.split.data(), sizeof(uint32_t) * h->kd.split.size(),
                             hipMemcpyHostToDevice, s));
+    }
+    {
+        const uint32_t nn = (uint32_t)h->kd.nodes.size();
+        k_leaf_boxes<<<(nn + 255) / 256 + (nn == 0), 256, 0, s>>>(h->d_kd_pn, nn, h->kd.root_ref, h->aabb[0], h->aabb[1], h->aabb[2],
+                                                               h->aabb[3], h->aabb[4], h->aabb[5], h->d_kd_lbox);
     }
     if (!h->kd.groups.empty())
         HIPC(hipMemcpyAsync(h->d_kd_gref, h->kd.groups.data(), sizeof(uint32_t) * h->kd.groups.size(),
@@ -855,6 +866,7 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     for (int d = 0; d < 6; ++d) M.bb[d] = h->aabb[d];
     M.kd_pts4 = h->d_kd_pts4;
     M.kd_apx4 = h->d_kd_apx4;
+    M.kd_lbox = h->d_kd_lbox;
     for (int d = 0; d < 3; ++d) M.apx_c[d] = h->apx_c[d];
     M.apx_kS = h->apx_centred ? 7.f : 5.f, M.apx_kQ = h->apx_centred ? 6.f : 4.f;
     M.kd_npos = h->fast_active ? (uint32_t)(FAST_GROUP * ((h->nv + FAST_GROUP - 1) / FAST_GROUP))
@@ -1672,7 +1684,7 @@ void sdfhip_destroy(sdfhip_t* h) {
                     h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
-                    h->topo.depthI, h->ws.qkeys, h->ws.qperm, h->ws.qbounds, h->d_gstack, h->d_kd_pts4, h->d_kd_apx4,
+                    h->topo.depthI, h->ws.qkeys, h->ws.qperm, h->ws.qbounds, h->d_gstack, h->d_kd_pts4, h->d_kd_apx4, h->d_kd_lbox,
                     h->ws.fb_list, h->ws.fb_count, h->ws.coop_list, h->ws.coop_state, h->ws.amb_mask, h->ws.amb_cnt, h->ws.amb_s1, h->ws.amb_s2,
                     h->d_vkeys, h->d_vidx};
     for (void* p : ptrs)
@@ -1928,11 +1940,11 @@ int sdfhip_debug_ray_stats(unsigned long long out[8], int reset) {
     }
     return 0;
 }
-int sdfhip_debug_packet_stats(unsigned long long out[8], int reset) {
+int sdfhip_debug_packet_stats(unsigned long long out[12], int reset) {
     HIPC(hipDeviceSynchronize());
-    HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_stats), 8 * sizeof(unsigned long long)));
+    HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_stats), 12 * sizeof(unsigned long long)));
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         HIPC(hipMemcpyToSymbol(HIP_SYMBOL(g_pk_stats), z, sizeof(z)));
     }
     return 0;

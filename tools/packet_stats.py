@@ -27,9 +27,9 @@ else:
 if a.repeat > 1:
     pts = pts.repeat_interleave(a.repeat, dim=0).contiguous()
 L = s._L
-st = (C.c_ulonglong * 8)()
+st = (C.c_ulonglong * 12)()
 L.sdfhip_debug_packet_stats(st, 1)
 s.nn(pts); torch.cuda.synchronize()
 L.sdfhip_debug_packet_stats(st, 1)
 w = max(1, st[0])
-print(f"{a.mesh} noise {a.noise} {'grid%d' % a.grid if a.grid else 'random'} n={pts.shape[0]} fast={a.fast_nn}: waves {st[0]}  per wave: quad nodes {st[1]/w:.1f}  groups {st[2]/w:.1f}  chunks {st[3]/w:.1f} (= {4*st[3]/w:.0f} vertex slots)  tie redos {st[4]/w:.2f}  pops {st[5]/w:.1f}  near-tie lanes (path check) {st[6]/w:.2f}  deferred lanes {st[7]/w:.3f}")
+print(f"{a.mesh} noise {a.noise} {'grid%d' % a.grid if a.grid else 'random'} n={pts.shape[0]} fast={a.fast_nn}: waves {st[0]}  per wave: quad nodes {st[1]/w:.1f}  groups {st[2]/w:.1f}  chunks {st[3]/w:.1f} (= {4*st[3]/w:.0f} vertex slots)  tie redos {st[4]/w:.2f}  pops {st[5]/w:.1f}  near-tie lanes (path check) {st[6]/w:.2f}  deferred lanes {st[7]/w:.3f}  path checks: leaf-box passes {st[8]/w:.2f} (failing the walk: {st[9]}, must be 0)  walks {st[10]/w:.3f}")
