@@ -1082,12 +1082,14 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             const int64_t packs = (deferred_pts + HEAVY_Q - 1) / HEAVY_Q;
             // How many queries the list holds is known on the device only.  A short list (2k of 125M on
             // the bench mesh) leaves the GPU empty with one 4-wave block per four queries, and one wave's
-            // chain over 190k positions is ~0.4 ms: 16 waves share each scan then (0.45 -> 0.39 ms).  A long
+            // chain over 190k positions is ~0.4 ms: 8 waves share each scan then (16 waves, two blocks per CU:
+            // 531 blocks for 2122 queries are two rounds of 512, the second nearly empty: nn 4M 2.05 -> 1.96 ms,
+            // 125M sdf step 20.73 -> 20.5 ms with 8).  A long
             // one (41k of 64M on the smooth icosphere-7) is throughput bound and 4-wave blocks are faster
             // (sdf 22.3 against 24.5 ms).  Both variants are launched; each returns at once outside its range.
             constexpr uint32_t HEAVY_SHORT = 8192;
             const int64_t g16 = packs < HEAVY_SHORT / HEAVY_Q ? packs : HEAVY_SHORT / HEAVY_Q;
-            k_query_heavy<HK, ROBUST, 16><<<(uint32_t)g16, 1024, 0, s>>>(
+            k_query_heavy<HK, ROBUST, 8><<<(uint32_t)g16, 512, 0, s>>>(
                 M, d_pts, W.fb_list + W.fb_cap, W.fb_count + 2, trunc, d_out, W.fb_list,
                 W.fb_count + flip, 0u, nullptr, 1u, HEAVY_SHORT);
             if (deferred_pts > (int64_t)HEAVY_SHORT)
