@@ -113,6 +113,11 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 
 // One chunk = four padded vertices = 64 B = one s_load_dwordx16.
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+// The chunk loads of the walk go through the CONSTANT address space: the tree arrays are never written while
+// a query kernel runs, and saying so keeps these wave-uniform loads scalar (s_load_dwordx16) wherever they
+// stand.  Through a generic pointer the compiler turns them into vector loads (2x slower walk) as soon as a
+// store, an atomic or a barrier can precede them on any path — behind a loop's back edge, for one.
+typedef const __attribute__((address_space(4))) u32x16* ChunkPtr;
 
 #ifdef SDFK_STATS
 // tuning build only (make stats): per-wave work counters of the packet pass
@@ -247,7 +252,7 @@ __device__ __forceinline__ void group_exact(const MeshDev& M, float qx, float qy
     const float4* P = M.kd_pts4 + first;
     uint32_t b = S.b, s2 = S.s2, h = S.h;
     const uint32_t b0 = b, s0 = s2, h0 = h;
-    const u32x16* C = (const u32x16*)__builtin_assume_aligned(P, 64);
+    const ChunkPtr C = (ChunkPtr)__builtin_assume_aligned(P, 64);
     uint32_t ci = 0;
 #if SDFK_CHUNK_BATCH >= 3
     for (; ci + 3u <= nch; ci += 3u) {
@@ -303,7 +308,7 @@ __device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y
                                              ApproxState& S) {
     const uint32_t nch = cur & 15u;
     const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
-    const u32x16* C = (const u32x16*)__builtin_assume_aligned(M.kd_apx4 + first, 64);
+    const ChunkPtr C = (ChunkPtr)__builtin_assume_aligned(M.kd_apx4 + first, 64);
     float gm = __builtin_inff();  // (a NaN never enters: fminf keeps the other operand)
 #define SDFK_APX_SLOT(A, O_)                                                               \
     __builtin_fmaf(X2, __uint_as_float(A[O_]),                                             \
@@ -785,6 +790,10 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
                                                          uint32_t off,
                                                          uint32_t* __restrict__ heavy_list,
                                                          uint32_t* __restrict__ heavy_cnt) {
+    // (One packet per wave.  A loop over consecutive packets — to fetch the next packet's points while this one
+    // walks — was tried once the chunk loads were in the constant address space: the compiler then hoists every
+    // kernel-argument load and every mesh-derived constant out of the loop and keeps them live, 91 VGPRs
+    // instead of 72 with the scalar registers spilled into vector lanes.)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     // lanes past the end of the batch repeat its last query (and write nothing): they then ask
