@@ -46,6 +46,12 @@ for name, (v, f, q) in cases.items():
     s.nn(q)
     s._L.sdfhip_debug_packet_stats(st, 1)
     out[name] = {"near_tie_lanes": int(st[6]), "box_passes": int(st[8]), "box_pass_walk_fail": int(st[9]), "walks": int(st[10])}
+    if name.startswith("torus, box"):  # the boxes follow update(): same queries against the moved, shrunk mesh
+        s.vertices_mutable = (v * np.float32(0.6) + np.float32([0.3, -0.2, 0.1])).astype(np.float32)
+        s.update()
+        s.nn(q)
+        s._L.sdfhip_debug_packet_stats(st, 1)
+        out[name + ", after update()"] = {"near_tie_lanes": int(st[6]), "box_passes": int(st[8]), "box_pass_walk_fail": int(st[9]), "walks": int(st[10])}
 print("RESULT " + json.dumps(out))
 """ % ROOT
 
