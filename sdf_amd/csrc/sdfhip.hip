@@ -1396,14 +1396,14 @@ int run_query_host(sdfhip_ctx* h, int kind, const float* pts, int64_t n, int tru
     auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count(); };
     auto upload = [&](int64_t c) {
         const int k = (int)(c & 1);
-        const double t0 = now_ms();
-        struct Done { bool on; int64_t c; double t0; decltype(now_ms)& f; ~Done() { if (on) std::fprintf(stderr, "[host] upload %lld: %.2f .. %.2f\n", (long long)c, t0, f()); } } done{dbg, c, t0, now_ms};
+        const double t0 = dbg ? now_ms() : 0.0;
         if (pg_in)
             e = bounce_h2d(h, h->d_stage_in[k], pts + 3 * start[c], sizeof(float) * 3 * (size_t)span(c), h->s_in);
         else
             e = hipMemcpyAsync(h->d_stage_in[k], pts + 3 * start[c], sizeof(float) * 3 * (size_t)span(c),
                                hipMemcpyHostToDevice, h->s_in);
         if (e == hipSuccess) e = hipEventRecord(h->ev_in[k], h->s_in);
+        if (dbg) std::fprintf(stderr, "[host] upload %lld: %.2f .. %.2f\n", (long long)c, t0, now_ms());
     };
     auto launch = [&](int64_t c) {
         const int k = (int)(c & 1);
