@@ -676,7 +676,9 @@ bool approx_pays(const sdfhip_ctx* h) {
     const double area = 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
     if (!(area > 0.0) || !std::isfinite(area) || !std::isfinite(S)) return false;
     const double lambda = (double)h->nv / area * 3.141592653589793 * 2.0 * E;
-    return lambda <= 0.3;
+    // (tori of 360k / 490k / 640k / 1M vertices, lambda = 0.34 / 0.47 / 0.61 / 0.95, 32M random points: nn 10.5 / 14.7 /
+    // 22.1 / 231 ms with the pass, 12.8 / 17.2 / 22.8 / 32.8 ms without: tools/scale_probe.py <res> approx=<0|1>)
+    return lambda <= 0.5;
 }
 
 // order `s` after the last asynchronous query of this handle (no-op on the same stream)

@@ -11,6 +11,8 @@ res = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 v, f = meshes.torus(res, res)
 R = meshes.random_rotation(1234)
 t0 = time.perf_counter(); s = sdf_amd.SDF(v, f); s.set_raycast_axes(R); print(f"mesh {v.shape[0]} v / {f.shape[0]} f: construct {1e3*(time.perf_counter()-t0):.1f} ms, stats {s.stats}")
+for kv in sys.argv[2:]:  # key=value handle options
+    s.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 t0 = time.perf_counter(); s.update(); print(f"update {1e3*(time.perf_counter()-t0):.1f} ms")
 dev = torch.device("cuda", 0)
 pts = torch.rand((32_000_000, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(7)).mul_(2).sub_(1)
