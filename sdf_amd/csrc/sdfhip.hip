@@ -664,21 +664,58 @@ int build_fast_tree(sdfhip_ctx* h) {
 // vertex density rho: lambda = rho * pi * 2E.  It pays while lambda is small: not for meshes far
 // from the origin against their size (S large), nor for very dense ones.  rho is taken from the
 // surface of the AABB, |q_i| ~ max|v_i|; both crude, the threshold is generous.
-bool approx_pays(const sdfhip_ctx* h) {
-    if (h->nv < 64) return false;
+// E: the absolute window of the approximate pass (Ea for a query at the mesh), lambda: vertices per window
+bool approx_window(const sdfhip_ctx* h, double& E, double& lambda) {
     double V[3], e[3];
     for (int d = 0; d < 3; ++d) {  // (the pass works in a frame centred on the mesh: V = half extents)
         V[d] = std::fmax(std::fabs((double)h->aabb[d] - h->apx_c[d]), std::fabs((double)h->aabb[d + 3] - h->apx_c[d]));
         e[d] = (double)h->aabb[d + 3] - (double)h->aabb[d];
     }
     const double S = 3.0 * (V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
-    const double E = 5.9604644775390625e-8 * (h->apx_centred ? 7.0 : 5.0) * S;
+    E = 5.9604644775390625e-8 * (h->apx_centred ? 7.0 : 5.0) * S;
     const double area = 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
     if (!(area > 0.0) || !std::isfinite(area) || !std::isfinite(S)) return false;
-    const double lambda = (double)h->nv / area * 3.141592653589793 * 2.0 * E;
+    lambda = (double)h->nv / area * 3.141592653589793 * 2.0 * E;
+    return true;
+}
+constexpr double APPROX_LAMBDA_MAX = 0.5;
+bool approx_pays(const sdfhip_ctx* h) {
+    if (h->nv < 64) return false;
+    double E, lambda;
+    if (!approx_window(h, E, lambda)) return false;
     // (tori of 360k / 490k / 640k / 1M vertices, lambda = 0.34 / 0.47 / 0.61 / 0.95, 32M random points: nn 10.5 / 14.7 /
     // 22.1 / 231 ms with the pass, 12.8 / 17.2 / 22.8 / 32.8 ms without: tools/scale_probe.py <res> approx=<0|1>)
-    return lambda <= 0.5;
+    return lambda <= APPROX_LAMBDA_MAX;
+}
+// The same question per packet group, once the groups exist: a mesh whose vertices crowd in one place (a fine
+// part in a coarse scene) passes the average test while every query that has the fine part nearest meets four
+// candidate groups and goes to the exact scan — a pass over all vertices each (424^2 torus + a copy shrunk to 1 %
+// beside it, 32M random points: nn 195 ms with the pass, 39 ms without).  Density of a group: its vertices over the
+// disc of its box's half diagonal.  Every fourth group is looked at; more than 2 % of the vertices seen in groups
+// denser than four times the limit on the average turn the pass off (a torus is twice as dense inside as outside,
+// and the limit on the average was tuned on tori).
+bool approx_pays_locally(const sdfhip_ctx* h) {
+    double E, lambda;
+    if (!approx_window(h, E, lambda)) return false;
+    const float* P = h->perm_pts4.data();
+    size_t seen = 0, dense = 0;
+    for (size_t g = 0; g < h->kd.groups.size(); g += 4) {
+        const uint32_t ref = h->kd.groups[g];
+        const size_t first = (size_t)((ref & sdfk::KD_REF_MASK) >> 4) << 2, n = 4u * (ref & 15u);
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        uint32_t cnt = 0;
+        for (size_t k = first; k < first + n; ++k) {
+            if (!(P[4 * k + 3] < FLT_MAX)) continue;  // sentinel slot
+            ++cnt;
+            for (int d = 0; d < 3; ++d) lo[d] = std::fmin(lo[d], P[4 * k + d]), hi[d] = std::fmax(hi[d], P[4 * k + d]);
+        }
+        if (cnt < 8) continue;
+        seen += cnt;
+        const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        const double r2 = 0.25 * (dx * dx + dy * dy + dz * dz);
+        if (!(2.0 * E * cnt <= 4.0 * APPROX_LAMBDA_MAX * r2)) dense += cnt;
+    }
+    return dense * 50 <= seen;
 }
 
 // order `s` after the last asynchronous query of this handle (no-op on the same stream)
@@ -784,6 +821,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     auto tq0 = std::chrono::steady_clock::now();
     h->kd.build_groups();
     h->vmax2 = std::nextafter(fill.get(), FLT_MAX);
+    if (h->approx_ok) h->approx_ok = approx_pays_locally(h);
     auto tq1 = std::chrono::steady_clock::now();
     const int rc_dev = dev_side.get();
     auto tq2 = std::chrono::steady_clock::now();

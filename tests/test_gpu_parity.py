@@ -581,3 +581,26 @@ def test_sphere_centre_queries_take_the_heavy_path():
     assert s.stats["last_heavy_points"] >= 64
     assert (n == o.nn(p)).all()
     assert same_float(s(p), o(p)).all()
+
+
+def test_automatic_walk_choice_looks_at_local_vertex_density(monkeypatch):
+    """A fine part in a coarse scene: the average vertex density admits the approximate pass, the density of the
+    fine part's groups does not (every query nearest to it would meet four candidate groups and go to the exact
+    scan).  The automatic choice must fall back to the exact walk there, and keep the pass on the plain torus."""
+    monkeypatch.delenv("SDFHIP_APPROX", raising=False)
+    v, f = meshes.torus(200, 200)
+    v2 = (v * np.float32(0.01) + np.float32([0.5, 0.0, 0.6])).astype(np.float32)
+    V = np.concatenate([v, v2])
+    F = np.concatenate([f, f + v.shape[0]]).astype(np.uint32)
+    rng = np.random.default_rng(4)
+    q = rng.uniform(-1, 1, (300000, 3)).astype(np.float32)
+    kinds = {}
+    for name, (vv, ff) in {"plain": (v, f), "fine part": (V, F)}.items():
+        s = SDF(vv, ff, robust=False)
+        s.set_option("scan_max", 0)
+        s.set_option("profile", 1)
+        got = s.nn(q)
+        kinds[name] = s.stats["last_kernel"]
+        o = po.OracleSDF(vv, ff, False)
+        assert (got == o.nn(q)).all()
+    assert kinds["plain"] == 3 and kinds["fine part"] == 2, kinds  # SDFHIP_KERNEL_PACKET_APPROX / _EXACT
