@@ -388,13 +388,17 @@ __device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y
 // kernel; this wave continues it over the L1 nodes j with j % nparts == part (the walk is redone from the
 // first L1 node with the saved, nearly final thresholds: groups met again are recognised per lane).
 // budget: work units (chunks evaluated + candidates tested) after which the wave gives up.
+// Returns 0 (done), 1 (gave up on the work budget) or 2: the packet is as wide as the mesh (queries spread over a
+// region much larger than the mesh: every group is a candidate for some lane) — nothing was done and the
+// queries go straight to the heavy list (no walk, no cooperative continuation); when that list is long the host
+// has the strict kernel answer it, each lane walking the tree for itself, instead of the exact scan.
 template <bool APPROX, bool CONT>
-__device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy, float qz, float ax, float ay,
+__device__ __forceinline__ uint32_t packet_walk(const MeshDev& M, float qx, float qy, float qz, float ax, float ay,
                                             float az, float Qe, float cm, ExactState& SE, ApproxState& SA,
                                             uint32_t part, uint32_t nparts, uint32_t budget) {
     const uint32_t lane = threadIdx.x & 63u;
     SDFK_COUNT(0, 1);
-    if (M.kd_ngroups == 0u) return false;
+    if (M.kd_ngroups == 0u) return 0u;
     // sphere around the wave's queries: centre of their bounding box, radius = farthest query
     const float cx = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(qx))) + pk_ord2f(wave_umax(pk_f2ord(qx))));
     const float cy = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(qy))) + pk_ord2f(wave_umax(pk_f2ord(qy))));
@@ -405,6 +409,7 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
     const float hy = __uint_as_float(wave_umax(__float_as_uint(fabsf(ey)))) * (1.f + 4.f * PK_EPS);
     const float hz = __uint_as_float(wave_umax(__float_as_uint(fabsf(ez)))) * (1.f + 4.f * PK_EPS);
     const float rho = __builtin_amdgcn_sqrtf(__builtin_fmaf(hx, hx, __builtin_fmaf(hy, hy, hz * hz))) * (1.f + PK_EPS);
+    if (!CONT && !M.fast && rho > 0.5f * M.obb_rm) return 2u;  // (wave-uniform; obb_rm = sum of the mesh's extents)
     // absolute slack of the box tests: 64u x (an upper bound of |c - centre of any box|)
     const float reach = ((fabsf(cx - M.obb_cm[0]) + fabsf(cy - M.obb_cm[1])) + fabsf(cz - M.obb_cm[2])) + (M.obb_rm + rho);
     const float Ew = 3.8146973e-6f * reach;
@@ -524,7 +529,7 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
                 if (__ballot(!(t > rr)) == 0ull) continue;
                 const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)o.tag, (int)g);
                 SDFK_PK_EVAL(ref)
-                if (work > (CONT ? budget : M.heavy_budget)) return true;  // give up (wave-uniform): the cooperative kernel / k_query_heavy takes over
+                if (work > (CONT ? budget : M.heavy_budget)) return 1u;  // give up (wave-uniform): the cooperative kernel / k_query_heavy takes over
                 if (moved) res = SDFK_PK_RES();  // tightened
             }
         }
@@ -532,7 +537,7 @@ __device__ __forceinline__ bool packet_walk(const MeshDev& M, float qx, float qy
 #undef SDFK_PK_RES
 #undef SDFK_PK_EVAL
 #undef SDFK_PK_REFRESH
-    return false;
+    return 0u;
 }
 
 // exact evaluation of one packet group for one lane (second phase of the approximate pass): the
@@ -814,15 +819,21 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
     const float INF = __builtin_inff();
     ApproxState A = {INF, INF, INF, INF, H_NONE, H_NONE, H_NONE};
     float Qf = 0.f, Ea = 0.f;
+    uint32_t wr;
     if (APPROX) {
         V3 qc;
         approx_model(M, p, qc, Qf, Ea);
-        pb.bailed = packet_walk<true, false>(M, p.x, p.y, p.z, qc.x, qc.y, qc.z, Qf + Ea,
-                                             (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A, 0u, 1u, M.heavy_budget);
+        wr = packet_walk<true, false>(M, p.x, p.y, p.z, qc.x, qc.y, qc.z, Qf + Ea,
+                                      (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A, 0u, 1u, M.heavy_budget);
     } else {
-        pb.bailed = packet_walk<false, false>(M, p.x, p.y, p.z, p.x, p.y, p.z, 0.f, 1.f, SE, A, 0u, 1u, M.heavy_budget);
+        wr = packet_walk<false, false>(M, p.x, p.y, p.z, p.x, p.y, p.z, 0.f, 1.f, SE, A, 0u, 1u, M.heavy_budget);
         if (SE.b == SE.tieb) SE.s2 = SE.b;  // a settled exact tie is a tie
         pb.b = __uint_as_float(SE.b), pb.s = __uint_as_float(SE.s2), pb.h = SE.h;
+    }
+    pb.bailed = wr == 1u;
+    if (wr == 2u) {  // (wave-uniform) a packet as wide as the mesh
+        packet_to_heavy(valid, i, src, off, amb_mask, amb_cnt, heavy_list, heavy_cnt);
+        return;
     }
     if (pb.bailed) {  // wave-uniform
         uint32_t slot = 0xFFFFFFFFu;
@@ -891,7 +902,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) SDFK_PK_SGPR void k_query_packet_c
         approx_model(M, p, qc, Qf, Ea);
         const bool over = packet_walk<true, true>(M, p.x, p.y, p.z, qc.x, qc.y, qc.z, Qf + Ea,
                                                   (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A,
-                                                  wave, (uint32_t)COOP_WAVES, max(M.coop_budget, M.heavy_budget / 4u));
+                                                  wave, (uint32_t)COOP_WAVES, max(M.coop_budget, M.heavy_budget / 4u)) != 0u;
         if (lane == 0) s_over[wave] = over ? 1u : 0u;
         if (wave != 0) {
             sS[wave][0][lane] = __float_as_uint(A.B1), sS[wave][1][lane] = __float_as_uint(A.B2);

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(QBLOCK) void k_query(MeshDev M, const float* __rest
                                                   const uint32_t* __restrict__ perm, int64_t n,
                                                   int trunc_aabb, void* __restrict__ out,
                                                   uint32_t* gstack, uint32_t depth_cap,
-                                                  const uint32_t* __restrict__ n_dev) {
+                                                  const uint32_t* __restrict__ n_dev, uint32_t n_min = 0u) {
     extern __shared__ uint32_t lds[];
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -591,9 +591,13 @@ __global__ __launch_bounds__(QBLOCK) void k_query(MeshDev M, const float* __rest
         // of near-equidistant vertices), so only every 4th lane takes one: less divergence
         // serialisation per wave, and the launch is tail-latency bound anyway.
         n = (int64_t)*n_dev;
-        if (tid & 3) return;
-        first = tid >> 2;
-        step = nthreads >> 2;
+        if (n <= (int64_t)n_min) return;  // (a short heavy list is the exact scan's)
+        // (a long list is not the sparse near-tie kind: whole packets as wide as the mesh were sent here, every lane works)
+        if (n <= 262144) {
+            if (tid & 3) return;
+            first = tid >> 2;
+            step = nthreads >> 2;
+        }
     }
     for (int64_t i = first; i < n; i += step) {
         const int64_t src = perm ? (int64_t)perm[i] : i;

@@ -952,7 +952,7 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
 // from device memory (fallback list of the packet kernel) and `n` only sizes the grid.
 template <int KIND, bool ROBUST>
 int launch_strict(sdfhip_ctx* h, const MeshDev& M, const float* d_pts, const uint32_t* perm, int64_t n,
-                  int trunc, void* d_out, const uint32_t* n_dev, hipStream_t s) {
+                  int trunc, void* d_out, const uint32_t* n_dev, hipStream_t s, uint32_t n_min = 0u) {
     const bool needs_kd = !(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST));
     const uint32_t depth = (uint32_t)(h->kd.depth > 0 ? h->kd.depth : 1);
     const int64_t blocks_full = (n + QBLOCK - 1) / QBLOCK;
@@ -965,12 +965,12 @@ int launch_strict(sdfhip_ctx* h, const MeshDev& M, const float* d_pts, const uin
             h->gstack_words = words;
         }
         k_query<KIND, ROBUST, true><<<(uint32_t)blocks, QBLOCK, 0, s>>>(M, d_pts, perm, n, trunc, d_out,
-                                                                        h->d_gstack, depth, n_dev);
+                                                                        h->d_gstack, depth, n_dev, n_min);
     } else {
         const size_t lds = needs_kd ? (size_t)(QBLOCK / 64) * depth * 192 * sizeof(uint32_t) : 0;
         const int64_t blocks = blocks_full < 0x7FFFFFFF ? blocks_full : 0x7FFFFFFF;
         k_query<KIND, ROBUST, false><<<(uint32_t)blocks, QBLOCK, lds, s>>>(M, d_pts, perm, n, trunc,
-                                                                           d_out, nullptr, depth, n_dev);
+                                                                           d_out, nullptr, depth, n_dev, n_min);
     }
     HIPC(hipGetLastError());
     return 0;
@@ -1128,6 +1128,13 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             // one (41k of 64M on the smooth icosphere-7) is throughput bound and 4-wave blocks are faster
             // (sdf 22.3 against 24.5 ms).  Both variants are launched; each returns at once outside its range.
             constexpr uint32_t HEAVY_SHORT = 8192;
+            // A very long list is not the near-symmetry kind: the batch is spread over a region much larger than
+            // the mesh and whole packets, as wide as the mesh, were sent here unwalked (packet_walk).  The scan
+            // costs a pass over every vertex per query (8M points in a box 300 x the mesh: 554 ms); the strict
+            // kernel, every lane walking the tree for itself, answers such far queries in ~5 ns each (51 ms) but
+            // has a floor of several ms.  Above heavy_strict queries the strict kernel takes the list (strict mode only).
+            const double hs = 4.0e10 / (double)(M.kd_npos ? M.kd_npos : 1u);
+            const uint32_t heavy_strict = fast ? 0xFFFFFFFFu : (uint32_t)(hs < 65536.0 ? 65536.0 : (hs > 4.0e9 ? 4.0e9 : hs));
             const int64_t g16 = packs < HEAVY_SHORT / HEAVY_Q ? packs : HEAVY_SHORT / HEAVY_Q;
             k_query_heavy<HK, ROBUST, 8><<<(uint32_t)g16, 512, 0, s>>>(
                 M, d_pts, W.fb_list + W.fb_cap, W.fb_count + 2, trunc, d_out, W.fb_list,
@@ -1135,8 +1142,14 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             if (deferred_pts > (int64_t)HEAVY_SHORT)
                 k_query_heavy<HK, ROBUST, 4><<<(uint32_t)(packs < 8192 ? packs : 8192), 256, 0, s>>>(
                     M, d_pts, W.fb_list + W.fb_cap, W.fb_count + 2, trunc, d_out, W.fb_list,
-                    W.fb_count + flip, 0u, nullptr, HEAVY_SHORT + 1u, 0xFFFFFFFFu);
+                    W.fb_count + flip, 0u, nullptr, HEAVY_SHORT + 1u, heavy_strict);
             HIPC(hipGetLastError());
+            if (!fast && deferred_pts > (int64_t)heavy_strict) {
+                const int64_t gp = deferred_pts < (int64_t)QBLOCK * 65536 ? deferred_pts : (int64_t)QBLOCK * 65536;
+                if (int rc = launch_strict<KIND, ROBUST>(h, M, d_pts, W.fb_list + W.fb_cap, gp, trunc, d_out, W.fb_count + 2,
+                                                         s, heavy_strict))
+                    return rc;
+            }
         }
         if (!fast) {
             const int64_t grid_pts = deferred_pts < (int64_t)QBLOCK * 4096 ? deferred_pts : (int64_t)QBLOCK * 4096;

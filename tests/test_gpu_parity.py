@@ -604,3 +604,21 @@ def test_automatic_walk_choice_looks_at_local_vertex_density(monkeypatch):
         o = po.OracleSDF(vv, ff, False)
         assert (got == o.nn(q)).all()
     assert kinds["plain"] == 3 and kinds["fine part"] == 2, kinds  # SDFHIP_KERNEL_PACKET_APPROX / _EXACT
+
+
+@pytest.mark.parametrize("half, n", [(300.0, 400_000), (30.0, 2_000_000)])
+def test_batches_spread_far_beyond_the_mesh(half, n):
+    """Queries spread over a box 30 / 300 times the mesh: Morton packets as wide as the mesh go to the heavy list
+    unwalked (packet_walk), and a heavy list this long is answered by the strict kernel instead of the exact scan
+    (8M such points: 554 -> 50 ms).  Results must not notice."""
+    v, f = meshes.torus(424, 424)
+    R = meshes.random_rotation(11)
+    s = SDF(v, f)
+    s.set_raycast_axes(R)
+    s.set_option("profile", 1)
+    o = po.OracleSDF(v, f, True, R)
+    q = (np.random.default_rng(21).uniform(-1, 1, (n, 3)) * half).astype(np.float32)
+    assert (s.nn(q) == o.nn(q)).all()
+    assert s.stats["last_heavy_points"] > 210_000  # (the strict kernel's share: above 4e10 / tree positions)
+    assert same_float(s(q), o(q)).all()
+    assert (s.contains(q) == o.contains(q)).all()
