@@ -10,6 +10,7 @@ builds the same structures.  One "step" = one pass of the hot path over the rank
 inputs resident in HBM when the timed region starts.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          # starts its N ranks itself (see spawn_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -18,6 +19,8 @@ Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,11 +45,86 @@ def parse():
     ap.add_argument("--mesh-res", type=int, default=424, help="torus tessellation (424 -> 359,552 faces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the 100-frame deforming-mesh split (configs[4]) in `extra`")
+    ap.add_argument("--c5-frames", type=int, default=100)
     ap.add_argument("--no-sort", action="store_true")
     # rehearsal of the N>1 path on a box with one GPU: every rank on cuda:0, mesh broadcast over gloo
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--one-device", action="store_true")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process becomes the parent of
+    N ranks started through torch.distributed.run — as a CHILD process, and before anything here has touched
+    the GPU runtime (`import torch` and `torch.cuda.device_count()` do not).  The ranks inherit stdout, so
+    rank 0's single JSON line is this command's output; the exit code is the launcher's (non-zero if any
+    rank failed)."""
+    if not a.one_device:
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: this node shows {have} GPU(s) "
+                             "(--one-device --backend gloo rehearses the N-rank path on one card)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    return subprocess.run(cmd, env=env).returncode
+
+
+def c5_split(v0, f, R, dev, frames, fast_nn):
+    """BASELINE.json configs[4]: `frames` frames of vertices_mutable + update() + contains() + nn() on the same
+    4M device-resident seeded points (demo.cpp:109-121 is the reference's only update loop).
+    Synchronous frames give the per-frame split; the same frames issued back to back give the pipelined rate."""
+    s = sdf_amd.SDF(v0, f, robust=True, copy=True, device=dev.index)
+    s.set_raycast_axes(R)
+    if fast_nn:
+        s.set_option("fast_nn", 1)
+    pts = torch.rand((4_000_000, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(7)).mul_(2).sub_(1)
+    y4 = 4 * v0[:, 1:2]
+
+    def frame_verts(t):
+        return (v0 * (1 + 0.05 * np.sin(2 * np.pi * t / 100 + y4))).astype(np.float32)
+
+    tu = tc = tn = kd = 0.0
+    warm = 2
+    for t in range(frames + warm):
+        vt = frame_verts(t)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        s.vertices_mutable = vt
+        s.update()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        c = s.contains(pts)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        k = s.nn(pts)
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        if t >= warm:
+            tu += t1 - t0
+            tc += t2 - t1
+            tn += t3 - t2
+            kd += s.stats["last_kd_build_ms"]
+    vs = [frame_verts(t) for t in range(min(frames, 20))]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    keep = None
+    for vt in vs:
+        s.vertices_mutable = vt
+        s.update()
+        keep = (s.contains(pts), s.nn(pts))
+    torch.cuda.synchronize(dev)
+    piped = (time.perf_counter() - t0) / len(vs) * 1e3
+    del keep, c, k
+    return {"frames": frames, "points_per_frame": 4_000_000, "update_ms": tu / frames * 1e3,
+            "kd_build_ms": kd / frames, "contains_ms": tc / frames * 1e3, "nn_ms": tn / frames * 1e3,
+            "frame_ms": (tu + tc + tn) / frames * 1e3, "pipelined_frame_ms": piped,
+            "nn_tie_rule": "lowest (Morton code, index)" if fast_nn else "nanoflann first-visited (reference)"}
 
 
 def cpu_baseline(v, f, R, seed):
@@ -77,15 +155,26 @@ def cpu_baseline(v, f, R, seed):
         dt = time.perf_counter() - t0
         n = n2
     return {"value": n / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+            # what kind of port: it flatters the CPU against the reference proper
+            "variant": "port (grid-filtered rays): ray candidates from a uniform grid over pre-rotated faces "
+                       "instead of the reference's R-tree search + per-candidate rotation (sdf.cpp:297-322); "
+                       "kd search and face distances as the reference",
             "sample": f"{n} of the step's uniform random points, same mesh and rotation, "
                       f"{dt:.1f} s wall, oracle/liboracle.so with {threads} threads"}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a))  # (nothing has touched the GPU yet: see spawn_ranks)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}",
+              file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SDFHIP_BENCH_ECHO_WORLD"):  # tests: which ranks did the launch produce?
+        open(os.path.join(os.environ["SDFHIP_BENCH_ECHO_WORLD"], f"rank{rank}_of_{world}"), "w").close()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     if a.one_device:
@@ -93,12 +182,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    ranks_seen = None  # ranks the collective backend really connected: an all_reduce of ones
     if world > 1:
         import torch.distributed as dist
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        ones = torch.ones(1, dtype=torch.int64, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
 
     # ---- mesh: built on rank 0, replicated by RCCL broadcast (sdf_amd/distributed.py) -------
     res = a.mesh_res
@@ -108,10 +201,14 @@ def main():
         v, f = meshes.torus(res, res)
         R = meshes.random_rotation(1234)
     if dist is not None:
-        from sdf_amd.distributed import broadcast_mesh
-        v, f, R = broadcast_mesh(v, f, R, src=0, device=dev if a.backend == "nccl" else "cpu")
-    s = sdf_amd.SDF(v, f, robust=True, copy=True, device=local)
-    s.set_raycast_axes(R)
+        # the library's own multi-GPU layer: mesh + R broadcast from rank 0 (RCCL over xGMI with "nccl"),
+        # every rank builds the same structures on its GPU
+        from sdf_amd.distributed import ShardedSDF
+        sh = ShardedSDF(v, f, robust=True, R=R, src=0, device=local)
+        s, v, f, R = sh.engine, sh.verts, sh.faces, sh.R
+    else:
+        s = sdf_amd.SDF(v, f, robust=True, copy=True, device=local)
+        s.set_raycast_axes(R)
     if a.no_sort:
         s.set_option("sort_queries", 0)
 
@@ -216,6 +313,11 @@ def main():
         s.update()
     extra["update_ms"] = s.stats["last_update_ms"]
     extra["kd_build_ms"] = s.stats["last_kd_build_ms"]
+    if world == 1 and not a.no_c5 and a.c5_frames > 0:
+        del pts, out
+        torch.cuda.empty_cache()
+        extra["c5_strict"] = c5_split(v, f, R, dev, a.c5_frames, False)
+        extra["c5_fast_nn"] = c5_split(v, f, R, dev, a.c5_frames, True)
     line = {
         "metric": "robust SDF evals/s, ~360k-face mesh",
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -227,6 +329,9 @@ def main():
                    "points_per_gpu": n, "faces": nf, "verts": nv, "sort_queries": not a.no_sort},
         "roofline": roofline,
     }
+    if world > 1:
+        line["rccl_ranks"] = ranks_seen if a.backend == "nccl" else None
+        line["collective"] = {"backend": a.backend, "all_reduce_of_ones": ranks_seen}
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(v, f, R, 7)
     line["extra"] = extra

@@ -93,7 +93,11 @@ int sdfhip_sdf_device(sdfhip_t* h, const float* d_points, int64_t n, int trunc_a
  * SDFHIP_NOALLOC_MAX_POINTS points per call (more: SDFHIP_E_INVALID); meshes whose kd-tree is
  * deeper than 40 levels are refused (SDFHIP_E_STATE).  All calls on one GPU — from any handle —
  * share that array: calls that overlap on one GPU (different handles on different streams) race;
- * calls on one handle are ordered as usual. */
+ * calls on one handle are ordered as usual.  Option "profile" does not time this entry (it would create
+ * events).  On a capturing stream (hipStreamBeginCapture, torch.cuda.graph) the call records its kernels and
+ * memsets into the graph and leaves the handle's cross-stream ordering events out of it: the caller orders
+ * graph launches against sdfhip_update and against queries on other streams, and captures again after an
+ * update (a graph holds the mesh's device pointers and sizes as they were at capture). */
 #define SDFHIP_NOALLOC_MAX_POINTS (1 << 20)
 int sdfhip_sdf_device_noalloc(sdfhip_t* h, const float* d_points, int64_t n, int trunc_aabb,
                               float* d_out, void* stream);
@@ -153,8 +157,14 @@ int sdfhip_sample_surface_device(sdfhip_t* h, int64_t n, uint64_t seed, float* d
 /* ---------------------------------------------------------------------------------------------
  * One sdf::SDF on several GPUs of one process (no counterpart: the reference is CPU-only, its
  * parallelism is maybe_parallel_for over point indices, util.cpp:7-29).  A group holds one handle per
- * listed device (an ordinal may repeat), all built from the same host arrays and the same ray-cast
- * rotation.  The host-pointer queries below replace SDF::operator() / contains / nn like their
+ * listed device (an ordinal may repeat), all holding the same mesh and the same ray-cast rotation.
+ * The mesh is built ONCE per create / update, like the single update() of sdf.cpp:31-73: member 0 uploads
+ * the vertices and builds the nanoflann-exact kd-tree on the host with all build threads; every other
+ * member receives the vertices and the built tree arrays (kd nodes, permuted vertices, group refs: ~6 MB at
+ * 180k vertices) device to device — hipMemcpyPeerAsync, i.e. over xGMI between two GPUs of a node — and runs
+ * only the device-side part of the update (per-face precompute, column grids, oriented boxes) on its own
+ * GPU, concurrently with member 0's host build.
+ * The host-pointer queries below replace SDF::operator() / contains / nn like their
  * single-handle namesakes: the N points are cut into contiguous ranges [r * ceil(N/G), ...), member r
  * evaluates its range on its own GPU (own host thread, staging buffers, stream and PCIe link) and
  * writes into the same range of `out`.  There is no data-path collective.  copy = 1: member 0 owns
@@ -173,6 +183,21 @@ int sdfhip_group_get_raycast_axes(const sdfhip_group_t* g, float R[9]);
 int sdfhip_group_sdf(sdfhip_group_t* g, const float* points, int64_t n, int trunc_aabb, float* out);
 int sdfhip_group_contains(sdfhip_group_t* g, const float* points, int64_t n, uint8_t* out);
 int sdfhip_group_nn(sdfhip_group_t* g, const float* points, int64_t n, int32_t* out);
+/* The same three queries on device-resident shards (no counterpart; the shape of BASELINE.json configs[3]:
+ * every GPU holds its own range of the points): member k evaluates counts[k] points at d_points[k] into
+ * d_out[k], both on member k's GPU, asynchronously on streams[k] (hipStream_t as void*; streams == NULL or
+ * streams[k] == NULL: the null stream of that GPU).  counts[k] may be 0 (pointers ignored).  The launches of
+ * the members are issued concurrently, one host thread per member; like the `_device` entry points of a single
+ * handle the call returns once everything is enqueued. */
+int sdfhip_group_sdf_device(sdfhip_group_t* g, const float* const* d_points, const int64_t* counts,
+                            int trunc_aabb, float* const* d_out, void* const* streams);
+int sdfhip_group_contains_device(sdfhip_group_t* g, const float* const* d_points, const int64_t* counts,
+                                 uint8_t* const* d_out, void* const* streams);
+int sdfhip_group_nn_device(sdfhip_group_t* g, const float* const* d_points, const int64_t* counts,
+                           int32_t* const* d_out, void* const* streams);
+/* sdfhip_group_update with the new vertex positions in a device buffer (float32 [n_verts,3]) on member 0's
+ * GPU, read on `stream` (the group's counterpart of sdfhip_update_from_device; copy = 1 groups only). */
+int sdfhip_group_update_from_device(sdfhip_group_t* g, const float* d_verts, void* stream);
 
 /* Statistics of the structures behind the handle (no counterpart in the reference). */
 typedef struct {
@@ -194,7 +219,9 @@ typedef struct {
     int64_t last_heavy_points;
     /* the kernel that answered (most of) the last query call: SDFHIP_KERNEL_* */
     int32_t last_kernel;
-    int32_t reserved;
+    /* host kd-tree builds this handle has run so far (create + updates).  In a group only member 0 builds:
+     * the other members' count stays 0 and their last_kd_build_ms is 0. */
+    int32_t kd_builds;
 } sdfhip_stats_t;
 enum {
     SDFHIP_KERNEL_NONE = 0,

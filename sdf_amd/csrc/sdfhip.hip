@@ -181,7 +181,12 @@ struct sdfhip_ctx {
     float4* d_kd_pts4 = nullptr;
     float4* d_kd_apx4 = nullptr;  // the approximate pass's centred copy (k_apx_fill)
     float4* d_kd_lbox = nullptr;  // per position: its leaf's tight box (k_leaf_boxes, kd_path_clear)
-    size_t kd_lbox_cap = 0;
+    size_t kd_lbox_cap = 0, kd_apx_cap = 0;  // (capacities of their own: the GPU-built tree of fast_nn has neither array)
+    // the strict tree the device arrays currently hold — built by this handle's own update, or by the leader of
+    // its group and copied device to device (group.h): depth, root ref, padded positions, internal nodes
+    int32_t kd_depth = 0;
+    uint32_t kd_root = 0, kd_npos = 0, kd_nnodes = 0;
+    int64_t kd_builds = 0;  // host kd-tree builds this handle has run (sdfhip_stats_t::kd_builds)
     float apx_c[3] = {0.f, 0.f, 0.f};
     bool apx_centred = false;
     float amb_c = 1.f, amb_c2 = 1.f;
@@ -718,6 +723,61 @@ bool approx_pays_locally(const sdfhip_ctx* h) {
     return dense * 50 <= seen;
 }
 
+// device arrays of the strict tree: `nnodes` internal nodes, `nalloc` padded positions.  d_kd_pts4 / d_kd_vind are
+// shared with the GPU-built tree of fast_nn (build_fast_tree grows them under kd_pos_cap); the approximate pass's
+// copy and the leaf boxes exist in strict mode only and keep capacities of their own — a fast_nn update may have
+// grown kd_pos_cap past what they were allocated for.
+int reserve_strict_tree(sdfhip_ctx* h, size_t nnodes, size_t nalloc) {
+    if (nnodes > h->kd_nodes_cap) {
+        if (int rc = dalloc(&h->d_kd_pn, 4 * nnodes)) return rc;
+        if (int rc = dalloc(&h->d_kd_split, nnodes)) return rc;
+        h->kd_nodes_cap = nnodes;
+    }
+    if (nalloc > h->kd_pos_cap) {
+        if (int rc = dalloc(&h->d_kd_pts4, nalloc)) return rc;
+        if (int rc = dalloc(&h->d_kd_vind, nalloc)) return rc;
+        h->kd_pos_cap = nalloc;
+    }
+    if (nalloc > h->kd_apx_cap) {
+        if (int rc = dalloc(&h->d_kd_apx4, nalloc)) return rc;
+        h->kd_apx_cap = nalloc;
+    }
+    if (nalloc > h->kd_lbox_cap) {
+        if (int rc = dalloc(&h->d_kd_lbox, 2 * nalloc)) return rc;
+        h->kd_lbox_cap = nalloc;
+    }
+    return 0;
+}
+
+// A group update (group.h): the leader builds the tree once and tells the other members how far it is.
+//   stage 1: the new vertices are enqueued on the leader's stream (ev_verts recorded behind them); the mesh
+//            AABB, the rotation and the centre of the approximate pass are final
+//   stage 2: every upload of the strict tree is enqueued (ev_tree recorded behind them); the scalars that
+//            describe the tree (kd_depth .. vmax2, approx_ok) are final
+// fail(): the leader's update ended with an error; waiting members give up with it.
+struct UpdateSync {
+    std::mutex mu;
+    std::condition_variable cv;
+    int stage = 0, rc = 0;
+    std::string err;
+    hipEvent_t ev_verts = nullptr, ev_tree = nullptr;
+    void post(int st) {
+        std::lock_guard<std::mutex> l(mu);
+        if (st > stage) stage = st;
+        cv.notify_all();
+    }
+    void fail_with(int code, const std::string& msg) {
+        std::lock_guard<std::mutex> l(mu);
+        if (!rc) rc = code ? code : SDFHIP_E_STATE, err = msg;
+        cv.notify_all();
+    }
+    int wait(int st) {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [&] { return stage >= st || rc != 0; });
+        return rc;
+    }
+};
+
 // order `s` after the last asynchronous query of this handle (no-op on the same stream)
 int wait_for_queries(sdfhip_ctx* h, hipStream_t s) {
     if (h->query_pending && h->last_query_stream != s) HIPC(hipStreamWaitEvent(s, h->ev_query, 0));
@@ -731,7 +791,7 @@ int mark_query(sdfhip_ctx* h, hipStream_t s) {
     return 0;
 }
 
-int do_update(sdfhip_ctx* h, bool draw_R) {
+int do_update(sdfhip_ctx* h, bool draw_R, UpdateSync* sync = nullptr) {
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = h->stream;
     if (int rc = wait_for_queries(h, s)) return rc;  // queries still in flight read what update rewrites
@@ -769,6 +829,10 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     if (h->nv)
         HIPC(hipMemcpyAsync(h->d_verts, h->h_verts, sizeof(float) * 3 * (size_t)h->nv,
                             hipMemcpyHostToDevice, s));
+    if (sync) {
+        HIPC(hipEventRecord(sync->ev_verts, s));
+        sync->post(1);
+    }
     if (h->opt_fast_nn) {
         // no host kd-tree: everything is built on the device, on one stream
         h->last_kd_ms = 0.f;
@@ -792,6 +856,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     // strict kd-tree on the host (sdf.cpp:32 kd_tree.rebuild())
     auto tk = std::chrono::steady_clock::now();
     h->kd.build(h->h_verts, h->nv, (int)h->opt_build_threads, h->aabb);
+    h->kd_builds++;
     h->last_kd_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk).count();
     // vertices in (padded) tree order; sentinel slots are far away: their distance is +inf
     const size_t npos = h->kd.pos_vert.size();
@@ -828,21 +893,7 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     if (rc_dev) return fail(rc_dev, "%s", dev_err.empty() ? "device-side update failed" : dev_err.c_str());
     if (h->kd.nodes.size() >= (size_t)KD_MARK) return fail(SDFHIP_E_INVALID, "kd-tree too large");
     if (int rc = reserve_groups(h, (uint32_t)h->kd.groups.size())) return rc;
-    if (h->kd.nodes.size() > h->kd_nodes_cap) {
-        if (int rc = dalloc(&h->d_kd_pn, 4 * h->kd.nodes.size())) return rc;
-        if (int rc = dalloc(&h->d_kd_split, h->kd.nodes.size())) return rc;
-        h->kd_nodes_cap = h->kd.nodes.size();
-    }
-    if (nalloc > h->kd_pos_cap) {
-        if (int rc = dalloc(&h->d_kd_pts4, nalloc)) return rc;
-        if (int rc = dalloc(&h->d_kd_vind, nalloc)) return rc;
-        if (int rc = dalloc(&h->d_kd_apx4, nalloc)) return rc;
-        h->kd_pos_cap = nalloc;
-    }
-    if (nalloc > h->kd_lbox_cap) {  // (the GPU-built tree of fast_nn has none: a capacity of its own)
-        if (int rc = dalloc(&h->d_kd_lbox, 2 * nalloc)) return rc;
-        h->kd_lbox_cap = nalloc;
-    }
+    if (int rc = reserve_strict_tree(h, h->kd.nodes.size(), nalloc)) return rc;
     {   // ambiguity factor of the packet pass: c = (1 + w_th + 4u) rounded up, w_th = u(3.02 D + 11.2)
         const double u = 5.9604644775390625e-8;
         const double w = u * (3.02 * (double)(h->kd.depth > 0 ? h->kd.depth : 1) + 11.2) + 4.0 * u;
@@ -874,6 +925,12 @@ int do_update(sdfhip_ctx* h, bool draw_R) {
     if (!h->kd.groups.empty())
         HIPC(hipMemcpyAsync(h->d_kd_gref, h->kd.groups.data(), sizeof(uint32_t) * h->kd.groups.size(),
                             hipMemcpyHostToDevice, s));
+    h->kd_depth = h->kd.depth, h->kd_root = h->kd.root_ref;
+    h->kd_npos = (uint32_t)npos, h->kd_nnodes = (uint32_t)h->kd.nodes.size();
+    if (sync) {  // (before the boxes: the other members build their own from the copied tree)
+        HIPC(hipEventRecord(sync->ev_tree, s));
+        sync->post(2);
+    }
     if (int rc = build_obbs(h, (uint32_t)h->kd.groups.size())) return rc;
     HIPC(hipStreamSynchronize(s));  // host arrays are pageable and rebuilt by the next update
     h->last_update_ms =
@@ -902,7 +959,7 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     }
     M.fast = h->fast_active ? 1 : 0;
     M.kd_vind = h->d_kd_vind;
-    M.kd_root = h->fast_active ? KD_LEAF : h->kd.root_ref;
+    M.kd_root = h->fast_active ? KD_LEAF : h->kd_root;
     for (int d = 0; d < 6; ++d) M.bb[d] = h->aabb[d];
     M.kd_pts4 = h->d_kd_pts4;
     M.kd_apx4 = h->d_kd_apx4;
@@ -910,7 +967,7 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     for (int d = 0; d < 3; ++d) M.apx_c[d] = h->apx_c[d];
     M.apx_kS = h->apx_centred ? 7.f : 5.f, M.apx_kQ = h->apx_centred ? 6.f : 4.f;
     M.kd_npos = h->fast_active ? (uint32_t)(FAST_GROUP * ((h->nv + FAST_GROUP - 1) / FAST_GROUP))
-                               : (uint32_t)h->kd.pos_vert.size();
+                               : h->kd_npos;
     // a wave may walk 1/8 of the tree (4 positions per chunk) before it hands its queries over
     M.heavy_budget = h->opt_heavy_budget > 0 ? (uint32_t)h->opt_heavy_budget
                                              : (M.kd_npos / 32u > 4096u ? M.kd_npos / 32u : 4096u);
@@ -954,7 +1011,7 @@ template <int KIND, bool ROBUST>
 int launch_strict(sdfhip_ctx* h, const MeshDev& M, const float* d_pts, const uint32_t* perm, int64_t n,
                   int trunc, void* d_out, const uint32_t* n_dev, hipStream_t s, uint32_t n_min = 0u) {
     const bool needs_kd = !(KIND == Q_DETAIL || (KIND == Q_CONTAINS && ROBUST));
-    const uint32_t depth = (uint32_t)(h->kd.depth > 0 ? h->kd.depth : 1);
+    const uint32_t depth = (uint32_t)(h->kd_depth > 0 ? h->kd_depth : 1);
     const int64_t blocks_full = (n + QBLOCK - 1) / QBLOCK;
     if (needs_kd && depth > (uint32_t)LDS_DEPTH_MAX) {
         const int64_t blocks = blocks_full < 4096 ? blocks_full : 4096;
@@ -1604,7 +1661,7 @@ const char* sdfhip_last_error(void) { return g_err.c_str(); }
 const char* sdfhip_version(void) { return "sdfhip 0.1 (gfx950)"; }
 
 static int create_impl(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, int robust,
-                       int copy, int device, sdfhip_t** out) {
+                       int copy, int device, sdfhip_t** out, bool first_update) {
     if ((nv && !verts) || (nf && !faces)) return fail(SDFHIP_E_INVALID, "null verts/faces");
     if (nv >= sdfk::KD_MAX_POINTS) return fail(SDFHIP_E_INVALID, "too many vertices (max %u)", sdfk::KD_MAX_POINTS);
     if (nf >= (1u << 30)) return fail(SDFHIP_E_INVALID, "too many faces");
@@ -1709,15 +1766,17 @@ static int create_impl(const float* verts, uint32_t nv, const uint32_t* faces, u
     }
     if (!rc && hipMemcpy(h->d_adj_off, h->adj_off.data(), sizeof(uint32_t) * ((size_t)nv + 1), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(SDFHIP_E_HIP, "upload of adjacency failed");
-    if (!rc) rc = do_update(h, true);  // sdf.cpp:28 update(false): same work, kd built once
+    // sdf.cpp:28 update(false): same work, kd built once.  (Not for the non-leading members of a group: they
+    // receive the leader's tree, group.h.)
+    if (!rc && first_update) rc = do_update(h, true);
     return rc;
 }
 
-int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, int robust,
-                  int copy, int device, sdfhip_t** out) {
+static int create_handle(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, int robust,
+                         int copy, int device, sdfhip_t** out, bool first_update) {
     if (!out) return fail(SDFHIP_E_INVALID, "out is null");
     *out = nullptr;
-    const int rc = guarded([&]() -> int { return create_impl(verts, nv, faces, nf, robust, copy, device, out); });
+    const int rc = guarded([&]() -> int { return create_impl(verts, nv, faces, nf, robust, copy, device, out, first_update); });
     if (rc && *out) {
         const std::string keep = g_err;
         sdfhip_destroy(*out);
@@ -1725,6 +1784,11 @@ int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32
         *out = nullptr;
     }
     return rc;
+}
+
+int sdfhip_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, int robust,
+                  int copy, int device, sdfhip_t** out) {
+    return create_handle(verts, nv, faces, nf, robust, copy, device, out, true);
 }
 
 void sdfhip_destroy(sdfhip_t* h) {
@@ -1834,11 +1898,32 @@ int sdfhip_sdf_device_noalloc(sdfhip_t* h, const float* p, int64_t n, int trunc,
             W = g_scratch_ws[h->device];
         }
         if (!W) return fail(SDFHIP_E_STATE, "no static scratch on device %d", h->device);
-        if (int rc = wait_for_queries(h, (hipStream_t)stream)) return rc;
-        h->W = W;  // every buffer of this call comes out of the static scratch; nothing is allocated
-        const int rc = run_query(h, Q_SDF, p, n, trunc, out, (hipStream_t)stream);
-        h->W = &h->ws;
-        if (n > 0)
+        // Under stream capture (hipStreamBeginCapture / torch.cuda.graph) the call only records its kernels and
+        // memsets into the graph.  The cross-stream ordering events of the handle stay out of it: an event
+        // recorded inside a capture belongs to the graph and could not be waited for by update() later.  The
+        // caller orders graph launches against update() and against queries on other streams, and captures
+        // again after an update (the graph holds the mesh's pointers and sizes as they were).
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) {
+            (void)hipGetLastError();
+            cap = hipStreamCaptureStatusNone;
+        }
+        const bool capturing = cap != hipStreamCaptureStatusNone;
+        if (!capturing)
+            if (int rc = wait_for_queries(h, (hipStream_t)stream)) return rc;
+        // Every buffer of this call comes out of the static scratch; nothing is allocated — no hipMalloc, and no
+        // event either: option "profile" times the other entry points only (ProfScope skips a fixed workspace).
+        struct UseScratch {  // the handle's own workspace is back whatever run_query does, exceptions included
+            sdfhip_ctx* h;
+            UseScratch(sdfhip_ctx* h_, QueryWs* W_) : h(h_) { h->W = W_; }
+            ~UseScratch() { h->W = &h->ws; }
+        };
+        int rc;
+        {
+            UseScratch use(h, W);
+            rc = run_query(h, Q_SDF, p, n, trunc, out, (hipStream_t)stream);
+        }
+        if (n > 0 && !capturing)
             if (int rc2 = mark_query(h, (hipStream_t)stream)) return rc ? rc : rc2;
         return rc;
     });
@@ -1919,8 +2004,9 @@ int sdfhip_adj_faces(const sdfhip_t* h, uint32_t v, const int32_t** ids) {
 }
 int sdfhip_get_stats(const sdfhip_t* h, sdfhip_stats_t* o) {
     if (!h || !o) return fail(SDFHIP_E_INVALID, "null handle/out");
-    o->kd_nodes = h->fast_active ? (int32_t)h->n_groups : (int32_t)h->kd.nodes.size();
-    o->kd_depth = h->fast_active ? 2 : h->kd.depth;
+    o->kd_nodes = h->fast_active ? (int32_t)h->n_groups : (int32_t)h->kd_nnodes;
+    o->kd_depth = h->fast_active ? 2 : h->kd_depth;
+    o->kd_builds = (int32_t)(h->kd_builds > 0x7FFFFFFF ? 0x7FFFFFFF : h->kd_builds);
     o->bvh_nodes = h->robust ? (int32_t)h->n_rnodes : 0;
     o->bvh_depth = (int32_t)h->bvh_depth;
     o->last_update_ms = h->last_update_ms;

@@ -40,7 +40,7 @@ class _Stats(C.Structure):
                 ("last_kd_build_ms", C.c_float), ("query_kernel_ms", C.c_double),
                 ("query_kernel_launches", C.c_int64), ("query_kernel_points", C.c_int64),
                 ("last_fallback_points", C.c_int64), ("last_heavy_points", C.c_int64),
-                ("last_kernel", C.c_int32), ("reserved", C.c_int32)]
+                ("last_kernel", C.c_int32), ("kd_builds", C.c_int32)]
 
 
 KERNEL_NAMES = {0: "none", 1: "k_query (strict)", 2: "k_query_packet<exact walk>", 3: "k_query_packet<approx walk>",
@@ -64,6 +64,8 @@ ABI_SYMBOLS = [
     "sdfhip_group_create", "sdfhip_group_destroy", "sdfhip_group_size", "sdfhip_group_member",
     "sdfhip_group_update", "sdfhip_group_set_raycast_axes", "sdfhip_group_get_raycast_axes",
     "sdfhip_group_sdf", "sdfhip_group_contains", "sdfhip_group_nn",
+    "sdfhip_group_sdf_device", "sdfhip_group_contains_device", "sdfhip_group_nn_device",
+    "sdfhip_group_update_from_device",
     "sdfhip_renderer_create", "sdfhip_renderer_destroy", "sdfhip_renderer_update",
     "sdfhip_renderer_render_depth", "sdfhip_renderer_render_mask", "sdfhip_renderer_render_nn",
     "sdfhip_renderer_depth", "sdfhip_renderer_contains", "sdfhip_renderer_nn",
@@ -145,6 +147,11 @@ def load_library():
     L.sdfhip_group_sdf.argtypes = [vp, _fp, C.c_int64, C.c_int, _fp]
     L.sdfhip_group_contains.argtypes = [vp, _fp, C.c_int64, _bp]
     L.sdfhip_group_nn.argtypes = [vp, _fp, C.c_int64, _ip]
+    pp, i64p = C.POINTER(C.c_void_p), C.POINTER(C.c_int64)
+    L.sdfhip_group_sdf_device.argtypes = [vp, pp, i64p, C.c_int, pp, pp]
+    L.sdfhip_group_contains_device.argtypes = [vp, pp, i64p, pp, pp]
+    L.sdfhip_group_nn_device.argtypes = [vp, pp, i64p, pp, pp]
+    L.sdfhip_group_update_from_device.argtypes = [vp, vp, vp]
     L.sdfhip_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.sdfhip_host_free.argtypes = [C.c_void_p]
     L.sdfhip_renderer_create.argtypes = [_fp, C.c_uint32, _up, C.c_uint32, C.c_int, C.c_int, C.c_float,
@@ -279,6 +286,68 @@ class GroupSDF:
 
     def update(self):
         _check(self._L.sdfhip_group_update(self._g))
+
+    def update_from_device(self, verts_tensor):
+        """update() with the new vertex positions in a (V, 3) float32 tensor on member 0's GPU"""
+        import torch
+        t = verts_tensor.contiguous().float()
+        if tuple(t.shape) != (self._nv, 3):
+            raise TypeError("verts tensor must have the shape of the mesh vertices")
+        s = torch.cuda.current_stream(t.device).cuda_stream
+        _check(self._L.sdfhip_group_update_from_device(self._g, t.data_ptr(), s))
+
+    @property
+    def devices(self):
+        return [int(self._L.sdfhip_device(self._L.sdfhip_group_member(self._g, k))) for k in range(len(self))]
+
+    def member_stats(self, k):
+        s = _Stats()
+        _check(self._L.sdfhip_get_stats(self._L.sdfhip_group_member(self._g, k), C.byref(s)))
+        return {name: getattr(s, name) for name, _ in _Stats._fields_}
+
+    def _query_device(self, kind, shards, trunc_aabb=False):
+        """`shards`: one (n_k, 3) float32 torch tensor per member, on that member's GPU (None or empty: that
+        member idles).  Returns one result tensor per member on the same GPU; asynchronous on each GPU's
+        current torch stream."""
+        import torch
+        G = len(self)
+        if len(shards) != G:
+            raise TypeError(f"one shard per member expected ({G}), got {len(shards)}")
+        devs = self.devices
+        dt = {"sdf": torch.float32, "contains": torch.uint8, "nn": torch.int32}[kind]
+        pts, outs = [], []
+        P, O, S = (C.c_void_p * G)(), (C.c_void_p * G)(), (C.c_void_p * G)()
+        N = (C.c_int64 * G)()
+        for k, t in enumerate(shards):
+            dev = torch.device("cuda", devs[k])
+            if t is None:
+                t = torch.empty((0, 3), dtype=torch.float32, device=dev)
+            if not (_is_torch(t) and t.is_cuda and t.device.index == devs[k]):
+                raise SdfHipError(f"shard {k} must be a torch tensor on cuda:{devs[k]}")
+            if t.dim() != 2 or t.shape[1] != 3:
+                raise TypeError("every shard must have shape (n, 3)")
+            t = t.contiguous().float()
+            o = torch.empty(t.shape[0], dtype=dt, device=dev)
+            pts.append(t), outs.append(o)
+            P[k], O[k], N[k] = t.data_ptr(), o.data_ptr(), t.shape[0]
+            S[k] = torch.cuda.current_stream(dev).cuda_stream
+        if kind == "sdf":
+            _check(self._L.sdfhip_group_sdf_device(self._g, P, N, int(trunc_aabb), O, S))
+        elif kind == "contains":
+            _check(self._L.sdfhip_group_contains_device(self._g, P, N, O, S))
+            outs = [o.bool() for o in outs]
+        else:
+            _check(self._L.sdfhip_group_nn_device(self._g, P, N, O, S))
+        return outs
+
+    def sdf_device(self, shards, trunc_aabb=False):
+        return self._query_device("sdf", shards, trunc_aabb)
+
+    def contains_device(self, shards):
+        return self._query_device("contains", shards)
+
+    def nn_device(self, shards):
+        return self._query_device("nn", shards)
 
     def set_raycast_axes(self, R, pin=True):
         R = np.ascontiguousarray(R, dtype=np.float32).reshape(9)

@@ -72,6 +72,18 @@ def _worker(rank, world, port, outdir):
         _, _, dt = s.sdf_local(pts)
         frames[f"c{t}"], frames[f"n{t}"], frames[f"d{t}"] = ct, nt, dt
         frames[f"v{t}"], frames[f"R{t}"] = s.verts.copy(), s.R.copy()
+    # a caller error on the source rank (wrong vertex count, malformed R) raises on EVERY rank before any
+    # payload is broadcast — no rank is left waiting in a collective — and the object stays usable
+    bad = 0
+    for kw in (dict(verts=np.zeros((7, 3), np.float32) if rank == 0 else None),
+               dict(R=np.eye(4, dtype=np.float32) if rank == 0 else None)):
+        try:
+            s.update(**kw)
+        except ValueError:
+            bad += 1
+    s.update(v0 if rank == 0 else None, meshes.random_rotation(7) if rank == 0 else None)
+    _, _, c_after = s.contains_local(pts)
+    frames["bad_raised"], frames["c_after"] = bad, c_after
     np.savez(os.path.join(outdir, f"f{rank}.npz"), **frames)
     dist.barrier()
     dist.destroy_process_group()
@@ -120,3 +132,24 @@ def test_two_rank_gloo_sharded_queries_match_single_process(tmp_path):
             lo, hi = int(g["lo"]), int(g["hi"])
             assert (fr[k][f"c{t}"] == rc[lo:hi]).all() and (fr[k][f"n{t}"] == rn[lo:hi]).all()
             assert (fr[k][f"d{t}"].view(np.uint32) == rd[lo:hi].view(np.uint32)).all()
+    oa = po.OracleSDF(v, f, True, meshes.random_rotation(7)).contains(pts)
+    for k, g in enumerate(got):
+        assert int(fr[k]["bad_raised"]) == 2  # both bad calls raised on both ranks, nobody hung
+        assert (fr[k]["c_after"] == oa[int(g["lo"]):int(g["hi"])]).all()
+
+
+def test_bench_gpus_flag_starts_that_many_ranks(tmp_path):
+    """`python bench.py --gpus N` must measure N ranks by itself: the parent starts the
+    ranks before anything touches the GPU.  Without a GPU every rank stops at bench.py's "needs a GPU" line —
+    after the launch, which is the part under test: the flag decides the world size."""
+    import subprocess
+    env = dict(os.environ, SDFHIP_BENCH_ECHO_WORLD=str(tmp_path))
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--one-device", "--points", "1000", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    seen = sorted(os.listdir(tmp_path))
+    assert seen == ["rank0_of_2", "rank1_of_2"], (seen, r.stderr[-2000:])
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs a GPU" in r.stderr  # a failing rank fails the command

@@ -87,11 +87,21 @@ def test_config5_deforming_mesh_frames():
     assert ((ana > 0) == s2.contains(pts))[far].all()
 
 
-def test_config5_full_size_pipelined_frames():
-    """BASELINE config 5 at its own size: torus 424 x 424 (359,552 faces), 4M device-resident points, frames of
-    vertices_mutable + update() + contains() + nn() issued back to back (the queries are asynchronous on the
-    stream; the host kd-tree build of frame t+1 overlaps the GPU work of frame t), results kept on the device
-    and a sample of every frame checked against the oracle afterwards."""
+def _perf_guards():
+    """Wall-clock guards (about 1.5 x the figures measured on an idle MI355X; each is the best of several
+    repeats, so a noisy neighbour has to be there every time).  SDFHIP_PERF_GUARDS=0 keeps the measurements
+    (printed) and drops the assertions, for boxes that are shared or throttled."""
+    import os
+    return os.environ.get("SDFHIP_PERF_GUARDS", "1") != "0"
+
+
+def test_config5_full_size_100_frames():
+    """BASELINE config 5 as stated: torus 424 x 424 (359,552 faces), 100 frames of vertices_mutable + update() +
+    contains() + nn() on the same 4M device-resident seeded points.  Pass 1 issues the frames back to back (the
+    queries are asynchronous on the stream; the host kd-tree build of frame t+1 overlaps the GPU work of frame
+    t) and keeps every frame's results on the device; six of the hundred frames are then checked against the
+    oracle on a sample.  Pass 2 runs the same frames synchronously for the per-frame split update / contains /
+    nn that SURVEY §8(d) asks for (bench.py reports the same split under extra.c5_strict / c5_fast_nn)."""
     import time
     import torch
     v0, f = meshes.torus(424, 424)
@@ -100,26 +110,53 @@ def test_config5_full_size_pipelined_frames():
     s.set_raycast_axes(R)
     dev = torch.device("cuda", 0)
     pts = torch.rand((4_000_000, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(7)).mul_(2).sub_(1)
-    frames = 8
-    vs = [(v0 * (1 + 0.05 * np.sin(2 * np.pi * t / 100 + 4 * v0[:, 1:2]))).astype(np.float32) for t in range(frames)]
+    frames, warm = 100, 2
+    y4 = 4 * v0[:, 1:2]
+    vs = [(v0 * (1 + 0.05 * np.sin(2 * np.pi * t / 100 + y4))).astype(np.float32) for t in range(frames)]
     res = []
-    for t in range(frames):
-        if t == 2:  # the first two frames warm the workspaces up
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        s.vertices_mutable = vs[t]
-        s.update()
-        res.append((s.contains(pts), s.nn(pts)))
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / (frames - 2) * 1e3
-    print(f"config 5, full size: {ms:.2f} ms per frame (update + contains(4M) + nn(4M))")
-    assert ms < 12.0  # measured 4.2 ms on MI355X; the bound only catches a lost overlap or a slow path
+    best = 1e9
+    for rep in range(2):
+        res = []
+        for t in range(frames):
+            if t == warm:  # the first two frames warm the workspaces up
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            s.vertices_mutable = vs[t]
+            s.update()
+            res.append((s.contains(pts), s.nn(pts)))
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / (frames - warm) * 1e3)
+    print(f"config 5, full size, {frames} frames back to back: {best:.2f} ms per frame (update + contains(4M) + nn(4M))")
+    if _perf_guards():
+        assert best < 6.0  # 3.6-3.9 ms on an idle MI355X; catches a lost overlap or a slow path
     sub = torch.randint(0, pts.shape[0], (3000,), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
     h = pts[sub].cpu().numpy()
-    for t in range(frames):
+    for t in (0, 1, 24, 50, 75, 99):
         o = po.OracleSDF(vs[t], f, True, R)
         assert (res[t][0][sub].cpu().numpy().astype(bool) == o.contains(h)).all()
         assert (res[t][1][sub].cpu().numpy() == o.nn(h)).all()
+    inside = [int(r[0].sum()) for r in res]
+    assert len(set(inside)) > 50  # the mesh really moved from frame to frame
+    del res
+    tu = tc = tn = 0.0
+    for t in range(frames):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        s.vertices_mutable = vs[t]
+        s.update()
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        c = s.contains(pts)
+        torch.cuda.synchronize()
+        d = time.perf_counter()
+        n = s.nn(pts)
+        torch.cuda.synchronize()
+        e = time.perf_counter()
+        if t >= warm:
+            tu, tc, tn = tu + (b - a), tc + (d - b), tn + (e - d)
+    k = (frames - warm) / 1e3
+    print(f"config 5 split per frame (synchronous): update {tu / k:.2f} ms  contains(4M) {tc / k:.2f} ms  nn(4M) {tn / k:.2f} ms")
+    assert int(c.sum()) == inside[-1] and n.shape[0] == pts.shape[0]
 
 
 def test_update_from_device_tensor():
@@ -200,9 +237,11 @@ def test_config4_mesh_grid256_oracle_sample():
     d = s(pts)
     torch.cuda.synchronize()
     best = 1e9
-    for _ in range(3):
+    for _ in range(5):
         t0 = time.perf_counter(); d = s(pts); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-    assert best < 8e-3, best  # 3.5 ms on an idle MI355X (5.1 in round 1); generous for a shared box
+    print(f"256^3 grid, 359,552-face torus: {best * 1e3:.2f} ms")
+    if _perf_guards():
+        assert best < 5e-3, best  # 3.3 ms on an idle MI355X (5.1 in round 1); best of five
     c, nn = s.contains(pts), s.nn(pts)
     assert bool(((d > 0) == c)[d != 0].all())
     g = torch.Generator(device=dev).manual_seed(3)

@@ -173,3 +173,34 @@ def test_fast_nn_heavy_wave_path_forced():
     assert (s.nn(pts) == want).all()
     assert s.stats["last_heavy_points"] > pts.shape[0] // 2
     assert same_float(s(pts), d).all()
+
+
+def test_fast_nn_on_then_off_on_a_tiny_mesh_with_moved_vertices():
+    """the approximate pass's vertex copy has a capacity of its own.  A fast_nn update may grow the
+    shared position capacity past it; back in strict mode with moved vertices (a differently padded tree) the
+    fill must not run past the older, smaller array."""
+    import sdf_amd
+    from oracle import pyoracle as po
+    from sdf_amd import meshes
+    from conftest import same_float
+    v, f = meshes.icosphere(1)  # 42 vertices
+    rng = np.random.default_rng(0)
+    s = sdf_amd.SDF(v, f, robust=True, copy=True)
+    R = meshes.random_rotation(2)
+    s.set_raycast_axes(R)
+    s.set_option("approx", 1)
+    pts = rng.uniform(-1.5, 1.5, (20_000, 3)).astype(np.float32)
+    for rnd in range(6):
+        s.set_option("fast_nn", 1)
+        s.update()
+        s.nn(pts)
+        # clustered vertices: many small kd leaves -> more padded positions than before
+        vv = v.copy()
+        vv[: 20 + 3 * rnd] *= np.float32(1.0 + 0.3 * rng.random())
+        vv += rng.normal(0, 1e-3, vv.shape).astype(np.float32)
+        s.vertices_mutable = vv
+        s.set_option("fast_nn", 0)
+        s.update()
+        o = po.OracleSDF(vv, f, True, R)
+        assert (s.nn(pts) == o.nn(pts)).all()
+        assert same_float(s(pts), o(pts)).all()

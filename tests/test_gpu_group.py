@@ -64,3 +64,86 @@ def test_group_update_replicates_vertices_and_one_rotation():
     g.update()
     assert np.array_equal(g.raycast_axes, Rp)
     assert same_float(g(pts[:30_000]), po.OracleSDF(vt, f, True, Rp)(pts[:30_000])).all()
+
+
+def _member_handle(g, k):
+    return g._L.sdfhip_group_member(g._g, k)
+
+
+def test_group_builds_the_tree_once_and_replicates_device_to_device():
+    """VERDICT r2 item 2: one kd build per create / update for the whole group (member 0, all build threads);
+    the other members receive vertices + tree device to device and never build (counter kd_builds), yet answer
+    bit for bit like the oracle — on host ranges and on device-resident shards."""
+    import torch
+    v, f = meshes.torus(200, 200)  # 40,000 v / 80,000 f
+    R = meshes.random_rotation(21)
+    g = GroupSDF(v, f, robust=True, devices=[0, 0, 0, 0])
+    g.set_raycast_axes(R)
+    single = SDF(v, f, robust=True)
+    single.set_raycast_axes(R)
+    single.update()
+    st = [g.member_stats(k) for k in range(4)]
+    assert st[0]["kd_builds"] == 1 and [x["kd_builds"] for x in st[1:]] == [0, 0, 0]
+    assert all(x["kd_nodes"] == st[0]["kd_nodes"] and x["kd_depth"] == st[0]["kd_depth"] for x in st)
+    assert all(x["last_kd_build_ms"] == 0.0 for x in st[1:])
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    sizes = [300_000, 0, 1, 170_003]  # ragged shards: an idle member, a single point
+    o = None
+    for frame in range(3):
+        if frame:
+            vt = (v * (1 + 0.05 * np.sin(2 * np.pi * frame / 100 + 4 * v[:, 1:2]))).astype(np.float32)
+            if frame == 1:
+                g.vertices_mutable[:] = vt
+                g.update()
+            else:  # vertices produced on the GPU
+                g.update_from_device(torch.from_numpy(vt).to(dev))
+                assert (g.vertices_mutable == vt).all()
+        else:
+            vt = v
+        st = [g.member_stats(k) for k in range(4)]
+        assert st[0]["kd_builds"] == 1 + frame and all(x["kd_builds"] == 0 for x in st[1:])
+        o = po.OracleSDF(vt, f, True, R)
+        shards = [torch.rand((n, 3), device=dev, generator=gen).mul_(2).sub_(1) for n in sizes]
+        d, c, k = g.sdf_device(shards), g.contains_device(shards), g.nn_device(shards)
+        torch.cuda.synchronize()
+        for m, n in enumerate(sizes):
+            assert d[m].shape[0] == n and c[m].shape[0] == n and k[m].shape[0] == n
+            take = min(n, 30_000)
+            if take == 0:
+                continue
+            hp = shards[m][:take].cpu().numpy()
+            assert same_float(d[m][:take].cpu().numpy(), o(hp)).all()
+            assert (c[m][:take].cpu().numpy() == o.contains(hp)).all()
+            assert (k[m][:take].cpu().numpy() == o.nn(hp)).all()
+        # every member holds the same structures: the same shard gives the same bits on each of them
+        same = [shards[0], shards[0], shards[0], shards[0]]
+        dd = g.sdf_device(same)
+        assert all(bool((dd[0].view(torch.int32) == x.view(torch.int32)).all()) for x in dd[1:])
+    # a group update costs the leader what a single handle's update costs: one build with all threads
+    kd_group, kd_single = [], []
+    for _ in range(5):
+        g.update()
+        single.update()
+        kd_group.append(g.member_stats(0)["last_kd_build_ms"])
+        kd_single.append(single.stats["last_kd_build_ms"])
+    print(f"kd build per update: group leader {min(kd_group):.2f} ms, single handle {min(kd_single):.2f} ms")
+    assert min(kd_group) < 2.0 * min(kd_single) + 0.5
+
+
+def test_group_fast_nn_followers_build_on_their_own_gpu():
+    v, f = meshes.torus(120, 120)
+    g = GroupSDF(v, f, robust=True, devices=[0, 0])
+    R = meshes.random_rotation(3)
+    g.set_raycast_axes(R)
+    L = g._L
+    assert L.sdfhip_set_option(_member_handle(g, 0), b"fast_nn", 1) == 0  # the leader's option leads
+    g.update()
+    pts = np.random.default_rng(4).uniform(-1, 1, (200_000, 3)).astype(np.float32)
+    n = g.nn(pts)
+    o = po.OracleSDF(v, f, True, R)
+    on = o.nn(pts)
+    dg, do = ((pts - v[n]) ** 2).sum(-1), ((pts - v[on]) ** 2).sum(-1)
+    assert np.allclose(dg, do, rtol=1e-6, atol=0)  # a nearest vertex (the tie rule differs by design)
+    assert (g.contains(pts) == o.contains(pts)).all()
+    assert g.member_stats(1)["kd_builds"] == 0 and g.member_stats(0)["kd_builds"] == 1

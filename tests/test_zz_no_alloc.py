@@ -70,3 +70,48 @@ def test_noalloc_entry_rejects_batches_beyond_its_limit():
     # exactly the limit is served, and equals the allocating entry point
     ref, res = _both(s, pts[: 1 << 20].contiguous())
     assert same_float(ref, res).all()
+
+
+def test_noalloc_entry_under_hip_graph_capture_and_with_profiling_on():
+    """the callers it is for: captured into a HIP graph (torch.cuda.graph: capture_error_mode "global" turns
+    any hipMalloc / event creation during the capture into an error), replayed twice on new inputs, against
+    sdfhip_sdf_device; option "profile" on must not make it create events"""
+    torch = _torch()
+    import sdf_amd
+    from sdf_amd import meshes
+    v, f = meshes.torus(83, 83)
+    s = sdf_amd.SDF(v, f, robust=True)
+    s.set_raycast_axes(meshes.random_rotation(8))
+    s.set_option("profile", 1)
+    L = s._L
+    dev = torch.device("cuda", 0)
+    n = 200_000
+    gen = torch.Generator(device=dev).manual_seed(9)
+    pts = torch.rand((n, 3), device=dev, generator=gen).mul_(2).sub_(1)
+    out = torch.zeros(n, dtype=torch.float32, device=dev)
+    # warm-up outside the capture (first-call lazy state of the runtime), on the capture stream
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        assert L.sdfhip_sdf_device_noalloc(s._h, pts.data_ptr(), n, 0, out.data_ptr(), side.cuda_stream) == 0
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        rc = L.sdfhip_sdf_device_noalloc(s._h, pts.data_ptr(), n, 0, out.data_ptr(),
+                                         torch.cuda.current_stream(dev).cuda_stream)
+        assert rc == 0, L.sdfhip_last_error()
+    launches_before = s.stats["query_kernel_launches"]
+    for seed in (1, 2):
+        new = torch.rand((n, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(seed)).mul_(2.2).sub_(1.1)
+        pts.copy_(new)
+        out.fill_(-3.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = torch.empty_like(out)
+        assert L.sdfhip_sdf_device(s._h, pts.data_ptr(), n, 0, ref.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert same_float(ref.cpu().numpy(), out.cpu().numpy()).all()
+    # profiling timed the two sdfhip_sdf_device calls only: the no-alloc entry created no event pair
+    assert s.stats["query_kernel_launches"] - launches_before == 2
+    # and the handle still serves ordinary large calls afterwards (its own workspace is back)
+    big = torch.rand((2_000_000, 3), device=dev, generator=gen).mul_(2).sub_(1)
+    assert bool(torch.isfinite(s(big)).all())

@@ -2,7 +2,7 @@
 """Small-batch latency of the host entry points (numpy in, numpy out), pybench.py-sized calls, with and without the exact scan."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/sdf_amd") else os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.getcwd())
 import sdf_amd
 from sdf_amd import meshes

@@ -22,5 +22,18 @@ full = s.gather(pts.shape[0], lo, hi, d, torch.float32)
 assert (full.view(np.uint32) == np.asarray(d).view(np.uint32)).all()
 s.update((v * 1.01).astype(np.float32), None)
 _, _, d2 = s.sdf_local(pts)
+# device path of update(): the broadcast tensor goes straight into sdfhip_update_from_device (no host hop in the
+# Python layer), also when the source rank's vertices already live on the GPU; checked against a plain handle
+import sdf_amd
+v3 = (v * 0.97).astype(np.float32)
+s.update(torch.from_numpy(v3).to(dev), R)
+ref = sdf_amd.SDF(v3, f, robust=True); ref.set_raycast_axes(R)
+_, _, d3 = s.sdf_local(pts)
+assert (np.asarray(d3).view(np.uint32) == ref(pts).view(np.uint32)).all() and (s.verts == v3).all()
+try:
+    s.update(np.zeros((5, 3), np.float32))
+    raise SystemExit("a wrong vertex count must raise")
+except ValueError:
+    pass
 print("nccl world-size-1 ok", full.shape, float(np.abs(np.asarray(d2) - np.asarray(d)).max()))
 dist.destroy_process_group()

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import sdf_amd
 from sdf_amd import meshes
 v, f = meshes.torus(424, 424)
