@@ -398,7 +398,7 @@ __device__ __forceinline__ ObbFrame obb_frame(double n, const double s[3], const
 }
 __device__ __forceinline__ void obb_store(float4* __restrict__ rec, uint32_t k, const ObbFrame& F, const double lo[3],
                                           const double hi[3], const float c[3], const double hmax[3], uint32_t tag,
-                                          bool have_h) {
+                                          bool have_h, float4* __restrict__ aos = nullptr /* the same record, contiguous */) {
     (void)lo, (void)hi;
     float h[3];
     bool ok = have_h;
@@ -411,24 +411,27 @@ __device__ __forceinline__ void obb_store(float4* __restrict__ rec, uint32_t k, 
 #pragma unroll
         for (int d = 0; d < 3; ++d) ok = ok && fabsf(F.R[a][d]) <= 2.f;
     }
+    float4 r0, r1, r2, r3;
     if (ok) {
-        rec[k] = make_float4(c[0], c[1], c[2], h[0]);
-        rec[64u + k] = make_float4(F.R[0][0], F.R[0][1], F.R[0][2], h[1]);
-        rec[128u + k] = make_float4(F.R[1][0], F.R[1][1], F.R[1][2], h[2]);
-        rec[192u + k] = make_float4(F.R[2][0], F.R[2][1], F.R[2][2], __uint_as_float(tag));
+        r0 = make_float4(c[0], c[1], c[2], h[0]);
+        r1 = make_float4(F.R[0][0], F.R[0][1], F.R[0][2], h[1]);
+        r2 = make_float4(F.R[1][0], F.R[1][1], F.R[1][2], h[2]);
+        r3 = make_float4(F.R[2][0], F.R[2][1], F.R[2][2], __uint_as_float(tag));
     } else {  // contains everything: always visited
         const float inf = __builtin_inff();
-        rec[k] = make_float4(0.f, 0.f, 0.f, inf);
-        rec[64u + k] = make_float4(1.f, 0.f, 0.f, inf);
-        rec[128u + k] = make_float4(0.f, 1.f, 0.f, inf);
-        rec[192u + k] = make_float4(0.f, 0.f, 1.f, __uint_as_float(tag));
+        r0 = make_float4(0.f, 0.f, 0.f, inf);
+        r1 = make_float4(1.f, 0.f, 0.f, inf);
+        r2 = make_float4(0.f, 1.f, 0.f, inf);
+        r3 = make_float4(0.f, 0.f, 1.f, __uint_as_float(tag));
     }
+    rec[k] = r0, rec[64u + k] = r1, rec[128u + k] = r2, rec[192u + k] = r3;
+    if (aos) aos[0] = r0, aos[1] = r1, aos[2] = r2, aos[3] = r3;
 }
 
 // one thread per packet group
 __global__ __launch_bounds__(64) void k_group_obb(const uint32_t* __restrict__ grefs, uint32_t ngroups,
                                                   const float4* __restrict__ pts4, const int32_t* __restrict__ vind,
-                                                  float4* __restrict__ gobb) {
+                                                  float4* __restrict__ gobb, float4* __restrict__ gobb_aos) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ngroups) return;
     const uint32_t ref = grefs[g];
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(64) void k_group_obb(const uint32_t* __restrict__ g
         for (int a = 0; a < 3; ++a)
             hmax[a] = fmax(hmax[a], fabs((double)F.R[a][0] * x + (double)F.R[a][1] * y + (double)F.R[a][2] * z));
     }
-    obb_store(gobb + 256u * (size_t)(g >> 6), g & 63u, F, lo, hi, c, hmax, ref, n > 0);
+    obb_store(gobb + 256u * (size_t)(g >> 6), g & 63u, F, lo, hi, c, hmax, ref, n > 0, gobb_aos + 4u * (size_t)g);
 }
 
 // one wave per L1 node (run of 64 consecutive groups): lane k handles the vertices of group k

@@ -122,7 +122,8 @@ typedef const __attribute__((address_space(4))) u32x16* ChunkPtr;
 #ifdef SDFK_STATS
 // tuning build only (make stats): per-wave work counters of the packet pass
 __device__ unsigned long long g_pk_stats[12];  // waves, wide tests, groups, chunks, tie redos, candidates, near ties, deferred,
-                                               // leaf-box passes, of those failing the path walk (must be 0), path walks
+                                               // leaf-box passes, of those failing the path walk (must be 0), path walks,
+                                               // waves that took their cube's list
 #define SDFK_COUNT(K, V) if ((threadIdx.x & 63) == 0) atomicAdd(&g_pk_stats[K], (unsigned long long)(V))
 #else
 #define SDFK_COUNT(K, V)
@@ -188,18 +189,22 @@ __device__ __forceinline__ float wave_readf(float v, uint32_t l) {
 // ends with the same (b, s, h) / (B1..B4, H1..H3) as the tree walk it replaces.
 // =========================================================================================
 constexpr float PK_EPS = 3.8146973e-6f;  // 2^-18
+constexpr uint32_t CUBE_CAP = 256;        // entries of one cube's list (four wide tests); longer: the cube is unusable
+constexpr uint32_t CUBE_NONE = 0xFFFFFFFFu;
 struct ObbLane {
     float dP;                 // squared distance from the packet centre to this lane's child box (lower bound)
     float nx, ny, nz, f0;     // half space containing the box: n.(x - c) <= -f0
     float pk;                 // f0 - |n - g| rho: packet-level bound against the thresholds' linear trend g
     uint32_t tag;             // group ref (group level)
 };
-// lane `lane` tests child `lane` of one node (rec: [4][64] float4, see k_group_obb) against c
+// one lane tests one box record against c.  `recp`: the lane's record, its four float4 `stride` apart — stride 64
+// for the lane-major node arrays ([4][64] float4, see k_group_obb: lane k reads child k with unit stride), 1 for
+// the per-group copy the cube lists gather from (kd_gobb_aos)
 template <bool PLANE>
-__device__ __forceinline__ ObbLane obb_wide(const float4* __restrict__ rec, uint32_t lane, float cx, float cy,
-                                            float cz, float Ew, float gx = 0.f, float gy = 0.f, float gz = 0.f,
-                                            float hx = 0.f, float hy = 0.f, float hz = 0.f) {
-    const float4 A = rec[lane], B = rec[64u + lane], C = rec[128u + lane], D = rec[192u + lane];
+__device__ __forceinline__ ObbLane obb_wide_at(const float4* __restrict__ recp, uint32_t stride, float cx, float cy,
+                                               float cz, float Ew, float gx = 0.f, float gy = 0.f, float gz = 0.f,
+                                               float hx = 0.f, float hy = 0.f, float hz = 0.f) {
+    const float4 A = recp[0], B = recp[stride], C = recp[2u * stride], D = recp[3u * stride];
     const float dx = cx - A.x, dy = cy - A.y, dz = cz - A.z;
     const float p0 = __builtin_fmaf(B.x, dx, __builtin_fmaf(B.y, dy, B.z * dz));
     const float p1 = __builtin_fmaf(C.x, dx, __builtin_fmaf(C.y, dy, C.z * dz));
@@ -229,6 +234,13 @@ __device__ __forceinline__ ObbLane obb_wide(const float4* __restrict__ rec, uint
         o.pk = o.f0 - __builtin_fmaf(fabsf(o.nx - gx), hx, __builtin_fmaf(fabsf(o.ny - gy), hy, fabsf(o.nz - gz) * hz));
     }
     return o;
+}
+// lane `lane` tests child `lane` of one node (rec: [4][64] float4) against c
+template <bool PLANE>
+__device__ __forceinline__ ObbLane obb_wide(const float4* __restrict__ rec, uint32_t lane, float cx, float cy,
+                                            float cz, float Ew, float gx = 0.f, float gy = 0.f, float gz = 0.f,
+                                            float hx = 0.f, float hy = 0.f, float hz = 0.f) {
+    return obb_wide_at<PLANE>(rec + lane, 64u, cx, cy, cz, Ew, gx, gy, gz, hx, hy, hz);
 }
 // sort key of a box distance: its bit pattern (non-negative floats order like integers); NaN -> 0 (nearest)
 __device__ __forceinline__ uint32_t obb_key(float dP, bool valid) {
@@ -415,7 +427,7 @@ __device__ __forceinline__ uint32_t packet_walk(const MeshDev& M, float qx, floa
     const float Ew = 3.8146973e-6f * reach;
     const float X2 = -2.f * ax, Y2 = -2.f * ay, Z2 = -2.f * az;  // (a: the query in the approximate pass's frame)
     const float c2 = M.amb_c2;
-    float rr;  // per lane: sqrt of the lane's threshold, with the slack of the plane test
+    float rr = __builtin_inff();  // per lane: sqrt of the lane's threshold, with the slack of the plane test (inf: prunes nothing)
 #define SDFK_PK_REFRESH()                                                                           \
     {                                                                                               \
         const float thr_ = APPROX ? fmaxf(SA.B1 + Qe, 0.f) * cm : __uint_as_float(SE.b) * c2;       \
@@ -437,10 +449,76 @@ __device__ __forceinline__ uint32_t packet_walk(const MeshDev& M, float qx, floa
     }
     uint32_t work = 0;  // chunks evaluated + candidates tested so far (wave-uniform)
     bool moved = false;
+    float gx, gy, gz;
+    // packet-level threshold: max over the lanes of rr_l - g.e_l (+ slack of the dot product)
+#define SDFK_PK_RES() \
+    (pk_ord2f(wave_umax(pk_f2ord(rr - __builtin_fmaf(gx, ex, __builtin_fmaf(gy, ey, gz * ez))))) + 2.f * PK_EPS * rho)
+    // The candidates of one wide test (box record O in the lanes' registers, ALIVE: lanes whose child passed the
+    // packet-level test): nearest first by the packet-level bound — the thresholds are final after the first few
+    // groups, and once the nearest remaining child fails the packet-level test all do — then the lane-level
+    // plane test, then the evaluation.
+#define SDFK_PK_CANDS(O, ALIVE)                                                                                   \
+    for (;;) {                                                                                                    \
+        const uint32_t key_ = (ALIVE) ? pk_f2ord((O).pk) : 0xFFFFFFFFu;                                           \
+        const uint32_t mk_ = wave_umin(key_);                                                                     \
+        if (mk_ == 0xFFFFFFFFu || pk_ord2f(mk_) > res) break;                                                     \
+        const uint32_t g_ = (uint32_t)__builtin_ctzll(__ballot(key_ == mk_));                                     \
+        if (lane == g_) ALIVE = false;                                                                            \
+        SDFK_COUNT(5, 1);                                                                                         \
+        ++work;                                                                                                   \
+        const float t_ = __builtin_fmaf(wave_readf((O).nx, g_), ex,                                               \
+                                        __builtin_fmaf(wave_readf((O).ny, g_), ey,                                \
+                                                       __builtin_fmaf(wave_readf((O).nz, g_), ez, wave_readf((O).f0, g_)))); \
+        if (__ballot(!(t_ > rr)) == 0ull) continue;                                                               \
+        const uint32_t ref_ = (uint32_t)__builtin_amdgcn_readlane((int)(O).tag, (int)g_);                         \
+        SDFK_PK_EVAL(ref_)                                                                                        \
+        /* give up (wave-uniform): the cooperative kernel / k_query_heavy takes over */                           \
+        if (work > (CONT ? budget : M.heavy_budget)) return 1u;                                                   \
+        if (moved) res = SDFK_PK_RES(); /* tightened */                                                           \
+    }
+    // ---- cube lists (k_cube_lists): the groups any query of this wave's cube can need were listed once per cube;
+    // the wave tests that list — lane k its k-th entry — instead of walking the two levels of boxes from the top.
+    if (!CONT && M.cube_nc != 0u) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) float* CFloatPtr;
+        typedef const __attribute__((address_space(4))) f32x4* CFloat4Ptr;
+        typedef const __attribute__((address_space(4))) uint32_t* CUintPtr;
+        const CFloatPtr par = (CFloatPtr)M.cube_par;  // {lo.xyz, cells per unit length .xyz}
+        // the cube of lane 0's query (any cube will do: the wave checks that all its queries lie in the cube's box)
+        const float q0x = wave_readf(qx, 0u), q0y = wave_readf(qy, 0u), q0z = wave_readf(qz, 0u);
+        const float top = (float)(M.cube_nc - 1u);
+        const float fx = fminf(fmaxf((q0x - par[0]) * par[3], 0.f), top);  // (NaN -> 0)
+        const float fy = fminf(fmaxf((q0y - par[1]) * par[4], 0.f), top);
+        const float fz = fminf(fmaxf((q0z - par[2]) * par[5], 0.f), top);
+        const uint32_t cube = __builtin_amdgcn_readfirstlane(((uint32_t)fx * M.cube_nc + (uint32_t)fy) * M.cube_nc + (uint32_t)fz);
+        const CFloat4Ptr hd = (CFloat4Ptr)M.cube_hdr + 3u * (size_t)cube;
+        const f32x4 H0 = hd[0], H1 = hd[1], H2 = hd[2];  // {c.xyz, count}, {h.xyz, -}, {g.xyz, -}
+        const uint32_t cnt = __float_as_uint(H0.w);
+        const bool inside = fabsf(qx - H0.x) <= H1.x && fabsf(qy - H0.y) <= H1.y && fabsf(qz - H0.z) <= H1.z;
+        if (cnt - 1u < CUBE_CAP && __ballot(!inside) == 0ull) {  // (wave-uniform; an unusable cube has count 0xFFFFFFFF)
+            SDFK_COUNT(11, 1);
+            const CUintPtr lst = (CUintPtr)M.cube_list + (size_t)CUBE_CAP * cube;
+            {   // entry 0 first and unconditionally: the cube-level exclusion assumes every wave has evaluated it
+                const uint32_t id0 = lst[0];
+                const uint32_t ref0 = __float_as_uint(((CFloat4Ptr)M.kd_gobb_aos)[4u * (size_t)id0 + 3u].w);
+                SDFK_PK_EVAL(ref0)
+            }
+            gx = H2.x, gy = H2.y, gz = H2.z;
+            float res = SDFK_PK_RES();
+            for (uint32_t base = 0; base < cnt; base += 64u) {
+                const uint32_t idx = base + lane;
+                const uint32_t id = M.cube_list[(size_t)CUBE_CAP * cube + (idx < cnt ? idx : 0u)];
+                const ObbLane o = obb_wide_at<true>(M.kd_gobb_aos + 4u * (size_t)id, 1u, cx, cy, cz, Ew, gx, gy, gz, hx, hy, hz);
+                SDFK_COUNT(1, 1);
+                bool alive = idx < cnt && idx != 0u && !(o.pk > res);
+                SDFK_PK_CANDS(o, alive)
+            }
+            return 0u;
+        }
+    }
     const uint32_t nrows = (M.kd_nl1 + 63u) >> 6;
     // ---- greedy descent: the nearest L1 node, its nearest group; evaluating it gives every lane a bound
     uint32_t j0, g0;
-    float gx, gy, gz;
     {
         uint32_t bkey = 0xFFFFFFFFu, brow = 0u;
         for (uint32_t row = 0; row < nrows; ++row) {
@@ -471,73 +549,170 @@ __device__ __forceinline__ uint32_t packet_walk(const MeshDev& M, float qx, floa
         if (!(fabsf(gx) <= 1.f && fabsf(gy) <= 1.f && fabsf(gz) <= 1.f)) gx = gy = gz = 0.f;
     }
     // ---- the walk: L1 rows -> candidate L1 nodes -> candidate groups -> plane test -> evaluation
-    // packet-level threshold: max over the lanes of rr_l - g.e_l (+ slack of the dot product)
-#define SDFK_PK_RES() \
-    (pk_ord2f(wave_umax(pk_f2ord(rr - __builtin_fmaf(gx, ex, __builtin_fmaf(gy, ey, gz * ez))))) + 2.f * PK_EPS * rho)
-#ifndef SDFK_ORD_L
-#define SDFK_ORD_L 1
-#endif
-#ifndef SDFK_ORD_G
-#define SDFK_ORD_G 1
-#endif
-    // Children are taken nearest first (by their packet-level bound): the thresholds are final after
-    // the first few groups, and once the nearest remaining child fails the packet-level test all do.
+    // Children are taken nearest first (by their packet-level bound), at both levels.
     for (uint32_t row = 0; row < nrows; ++row) {
         const ObbLane o1 = obb_wide<true>(M.kd_l1obb + 256u * (size_t)row, lane, cx, cy, cz, Ew, gx, gy, gz, hx, hy, hz);
         SDFK_COUNT(1, 1);
         float res = SDFK_PK_RES();
         bool alive1 = 64u * row + lane < M.kd_nl1 && !(o1.pk > res) && (!CONT || (64u * row + lane) % nparts == part);
-        unsigned long long m1 = __ballot(alive1);
         for (;;) {
-            uint32_t k;
-            if (SDFK_ORD_L) {
-                const uint32_t key = alive1 ? pk_f2ord(o1.pk) : 0xFFFFFFFFu;
-                const uint32_t mk = wave_umin(key);
-                if (mk == 0xFFFFFFFFu || pk_ord2f(mk) > res) break;
-                k = (uint32_t)__builtin_ctzll(__ballot(key == mk));
-                if (lane == k) alive1 = false;
-            } else {
-                if (!m1) break;
-                k = (uint32_t)__builtin_ctzll(m1);
-                m1 &= m1 - 1ull;
-                if (wave_readf(o1.pk, k) > res) continue;
-            }
+            const uint32_t key = alive1 ? pk_f2ord(o1.pk) : 0xFFFFFFFFu;
+            const uint32_t mk = wave_umin(key);
+            if (mk == 0xFFFFFFFFu || pk_ord2f(mk) > res) break;
+            const uint32_t k = (uint32_t)__builtin_ctzll(__ballot(key == mk));
+            if (lane == k) alive1 = false;
             const uint32_t j = 64u * row + k;
             const uint32_t cnt = min(64u, M.kd_ngroups - 64u * j);
             const ObbLane o = obb_wide<true>(M.kd_gobb + 256u * (size_t)j, lane, cx, cy, cz, Ew, gx, gy, gz, hx, hy, hz);
             SDFK_COUNT(1, 1);
-            bool alive = lane < cnt && !(o.pk > res) && !(j == j0 && lane == g0);  // (g0: evaluated by the greedy descent)
-            unsigned long long m2 = __ballot(alive);
-            for (;;) {
-                uint32_t g;
-                if (SDFK_ORD_G) {
-                    const uint32_t key = alive ? pk_f2ord(o.pk) : 0xFFFFFFFFu;
-                    const uint32_t mk = wave_umin(key);
-                    if (mk == 0xFFFFFFFFu || pk_ord2f(mk) > res) break;
-                    g = (uint32_t)__builtin_ctzll(__ballot(key == mk));
-                    if (lane == g) alive = false;
-                } else {
-                    if (!m2) break;
-                    g = (uint32_t)__builtin_ctzll(m2);
-                    m2 &= m2 - 1ull;
-                }
-                SDFK_COUNT(5, 1);
-                ++work;
-                const float t = __builtin_fmaf(wave_readf(o.nx, g), ex,
-                                               __builtin_fmaf(wave_readf(o.ny, g), ey,
-                                                              __builtin_fmaf(wave_readf(o.nz, g), ez, wave_readf(o.f0, g))));
-                if (__ballot(!(t > rr)) == 0ull) continue;
-                const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)o.tag, (int)g);
-                SDFK_PK_EVAL(ref)
-                if (work > (CONT ? budget : M.heavy_budget)) return 1u;  // give up (wave-uniform): the cooperative kernel / k_query_heavy takes over
-                if (moved) res = SDFK_PK_RES();  // tightened
-            }
+            // (g0: evaluated by the greedy descent.  Not so in a continuation: the main kernel may have taken its
+            // cube's list, whose first group is the cube's, not this wave's — the group is evaluated again, which
+            // the lists take as the identity: a lane that holds it among its first three skips it (DEDUPE), for the
+            // others its minimum is >= their fourth)
+            bool alive = lane < cnt && !(o.pk > res) && (CONT || !(j == j0 && lane == g0));
+            SDFK_PK_CANDS(o, alive)
         }
     }
+#undef SDFK_PK_CANDS
 #undef SDFK_PK_RES
 #undef SDFK_PK_EVAL
 #undef SDFK_PK_REFRESH
     return 0u;
+}
+
+// =========================================================================================
+// Cube lists.  A wave's walk spends most of its instructions finding its ~30 candidate groups: ~14 wide box
+// tests over the two levels, one dependent 4 KB load each, for ~12 evaluated groups.  Neighbouring waves find
+// nearly the same candidates.  So the query domain (the bounds of the running launch's points) is cut into
+// nc^3 cubes holding a few thousand queries each, and ONE wave per cube lists, once, every group that any
+// query inside the cube can need; the ~60 waves whose queries lie in that cube then test the list — lane k its
+// k-th entry, one or two wide tests — instead of walking from the top.
+//
+// What a list must hold.  Every wave that uses it evaluates entry 0 (the group G0 nearest to the cube's centre
+// c) first.  After that, lane l (query q = c + e, |e_i| <= h_i, |e| <= rho) has a threshold
+//     thr(q) <= (D_q(v0) [exact walk]  |  a_q(v0) + Qf + Ea <= d^2(q, v0) + 2 Ea [approximate walk]) * (1 + ~1e-5)
+// for the vertex v0 of G0 nearest to c, and thresholds only shrink.  With d0 = |c - v0|, g = (c - v0) / d0:
+//     |q - v0| = sqrt(d0^2 + 2 d0 g.e + |e|^2) <= d0 + g.e + rho^2 / (2 d0)          (sqrt(1 + x) <= 1 + x / 2)
+// or, near the surface (d0 <= rho),  |q - v0| <= d0 + rho  with g = 0.  Hence for every query of the cube
+//     rr(q) - g.e  <=  res := (d0 + min-form slack + sqrt(2 Ea_max)) (1 + 2^-15) + 2^-15 reach,
+// and a group whose box lies in the half space {x : n.(x - c) <= -f0} can be left out when
+//     f0 - sum_i |n_i - g_i| h_i > res      (then f0 + n.e > rr(q) for every q of the cube: the walk's own
+//                                            lane-level test, at thresholds no smaller than the final ones)
+// — the packet-level test of the walk with the cube in the packet's place.  Everything left out is farther from
+// every query of the cube than that query's final threshold, exactly what the walk guarantees of the groups it
+// prunes itself; the waves' results cannot depend on whether they took the list or walked.
+// A wave uses a list only if all its queries lie inside the cube's stored box (checked in the wave, by
+// coordinates; the cube index is only a guess at where to look) and the list did not overflow.  Waves that
+// straddle two cubes, outliers beyond the sampled bounds, cubes as wide as the mesh: the ordinary walk.
+// =========================================================================================
+__global__ __launch_bounds__(64) void k_cube_lists(MeshDev M, const uint32_t* __restrict__ qbounds, uint32_t nc,
+                                                   float* __restrict__ par, float4* __restrict__ hdr,
+                                                   uint32_t* __restrict__ list) {
+    const uint32_t lane = threadIdx.x, cube = blockIdx.x;
+    const uint32_t ci[3] = {cube / (nc * nc), (cube / nc) % nc, cube % nc};
+    float c[3], h[3];
+    bool ok = M.kd_ngroups != 0u;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float lo = pk_ord2f(qbounds[d]), ext = pk_ord2f(qbounds[3 + d]) - lo;
+        const bool span = ext > 0.f && ext <= FLT_MAX;
+        const float w = span ? ext / (float)nc : 0.f;
+        if (cube == 0u && lane == 0u) par[d] = lo, par[3 + d] = span ? (float)nc / ext : 0.f;
+        c[d] = lo + ((float)ci[d] + 0.5f) * w;
+        // the cell's half width, a little wider: a query the waves' index arithmetic puts in this cube lies in its box
+        h[d] = 0.5f * w * 1.001f + 1e-6f * fabsf(c[d]);
+        ok = ok && fabsf(c[d]) <= FLT_MAX && h[d] <= FLT_MAX;
+    }
+    float4* H = hdr + 3u * (size_t)cube;
+    uint32_t* L = list + (size_t)CUBE_CAP * cube;
+    const float rho = __builtin_amdgcn_sqrtf(__builtin_fmaf(h[0], h[0], __builtin_fmaf(h[1], h[1], h[2] * h[2]))) * (1.f + PK_EPS);
+    ok = ok && rho <= 0.5f * M.obb_rm;  // (a cube as wide as the mesh: every group is a candidate)
+    if (!ok) {  // block-uniform
+        if (lane == 0u) H[0] = make_float4(0.f, 0.f, 0.f, __uint_as_float(CUBE_NONE));
+        return;
+    }
+    const float cx = c[0], cy = c[1], cz = c[2];
+    // half extents as the tests see them (margin for the dot products, as in packet_walk)
+    const float hx = h[0] * (1.f + 8.f * PK_EPS), hy = h[1] * (1.f + 8.f * PK_EPS), hz = h[2] * (1.f + 8.f * PK_EPS);
+    const float reach = ((fabsf(cx - M.obb_cm[0]) + fabsf(cy - M.obb_cm[1])) + fabsf(cz - M.obb_cm[2])) + (M.obb_rm + rho);
+    const float Ew = 3.8146973e-6f * reach;
+    const uint32_t nrows = (M.kd_nl1 + 63u) >> 6;
+    // ---- G0: the nearest L1 node to c, its nearest group (the greedy descent of packet_walk)
+    uint32_t j0, g0, ref0;
+    {
+        uint32_t bkey = 0xFFFFFFFFu, brow = 0u;
+        for (uint32_t row = 0; row < nrows; ++row) {
+            const ObbLane o = obb_wide<false>(M.kd_l1obb + 256u * (size_t)row, lane, cx, cy, cz, Ew);
+            const uint32_t key = obb_key(o.dP, 64u * row + lane < M.kd_nl1);
+            if (key < bkey) bkey = key, brow = row;
+        }
+        const uint32_t mkey = wave_umin(bkey);
+        const uint32_t who = (uint32_t)__builtin_ctzll(__ballot(bkey == mkey));
+        j0 = 64u * (uint32_t)__builtin_amdgcn_readlane((int)brow, (int)who) + who;
+        const uint32_t cnt = min(64u, M.kd_ngroups - 64u * j0);
+        const ObbLane o = obb_wide<false>(M.kd_gobb + 256u * (size_t)j0, lane, cx, cy, cz, Ew);
+        const uint32_t key = obb_key(o.dP, lane < cnt);
+        const uint32_t mk = wave_umin(key);
+        g0 = (uint32_t)__builtin_ctzll(__ballot(key == mk));
+        ref0 = (uint32_t)__builtin_amdgcn_readlane((int)o.tag, (int)g0);
+    }
+    // ---- v0: the vertex of G0 nearest to c (lane k looks at slot k: a group has at most 60 slots)
+    float d0, gx, gy, gz;
+    {
+        const uint32_t first = ((ref0 & sdfk::KD_REF_MASK) >> 4) << 2, nslots = 4u * (ref0 & 15u);
+        const float4 P = M.kd_pts4[first + (lane < nslots ? lane : 0u)];
+        const float dx = cx - P.x, dy = cy - P.y, dz = cz - P.z;
+        float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+        if (!(lane < nslots) || !(d2 <= FLT_MAX)) d2 = __builtin_inff();  // (sentinel slots lie at 3e38)
+        const uint32_t mk = wave_umin(__float_as_uint(d2));  // (non-negative floats order like their bits)
+        const uint32_t who = (uint32_t)__builtin_ctzll(__ballot(__float_as_uint(d2) == mk));
+        const float d2min = __uint_as_float(mk);
+        if (!(d2min <= FLT_MAX)) {  // wave-uniform: no finite vertex there
+            if (lane == 0u) H[0] = make_float4(0.f, 0.f, 0.f, __uint_as_float(CUBE_NONE));
+            return;
+        }
+        // an upper bound of |c - v0| (the fp32 d2 is within a few ulp: 2^-18 relative + a denormal-proof absolute term)
+        d0 = __builtin_amdgcn_sqrtf(d2min) * (1.f + PK_EPS) + 1e-30f;
+        const float wx = wave_readf(dx, who), wy = wave_readf(dy, who), wz = wave_readf(dz, who);
+        const bool trend = d0 > rho;  // far enough for the linear trend to pay
+        const float inv = trend ? 1.f / d0 : 0.f;
+        gx = wx * inv, gy = wy * inv, gz = wz * inv;
+        // Ea_max: the approximate pass's error bound Ea(q) = u (kS S + kQ Q) over the cube (|q - apx_c|_i <= m_i)
+        const float m0 = fabsf(cx - M.apx_c[0]) + hx, m1 = fabsf(cy - M.apx_c[1]) + hy, m2 = fabsf(cz - M.apx_c[2]) + hz;
+        const float V0 = fmaxf(fabsf(M.bb[0] - M.apx_c[0]), fabsf(M.bb[3] - M.apx_c[0]));
+        const float V1 = fmaxf(fabsf(M.bb[1] - M.apx_c[1]), fabsf(M.bb[4] - M.apx_c[1]));
+        const float V2 = fmaxf(fabsf(M.bb[2] - M.apx_c[2]), fabsf(M.bb[5] - M.apx_c[2]));
+        const float S = M.vmax2 + 2.f * ((m0 * V0 + m1 * V1) + m2 * V2);
+        const float Q = (m0 * m0 + m1 * m1) + m2 * m2;
+        const float Ea = 5.9604645e-8f * (M.apx_kS * S + M.apx_kQ * Q) * 1.01f;
+        const float slack = trend ? (rho * rho) * (0.5f * inv) : rho;
+        d0 = ((d0 + slack) + __builtin_amdgcn_sqrtf(2.f * Ea) * 1.001f) * (1.f + 3.0517578e-5f) + 3.0517578e-5f * reach;
+    }
+    const float res = d0;  // >= rr(q) - g.e of every query of the cube once G0 is evaluated
+    // ---- every group the cube-level test cannot exclude, in tree order (slot 0 is G0's)
+    uint32_t cnt = 1u;
+    const unsigned long long lt = lane == 0u ? 0ull : (~0ull >> (64u - lane));
+    for (uint32_t row = 0; row < nrows; ++row) {
+        const ObbLane o1 = obb_wide<true>(M.kd_l1obb + 256u * (size_t)row, lane, cx, cy, cz, Ew, gx, gy, gz, hx, hy, hz);
+        unsigned long long m1 = __ballot(64u * row + lane < M.kd_nl1 && !(o1.pk > res));
+        while (m1) {
+            const uint32_t j = 64u * row + (uint32_t)__builtin_ctzll(m1);
+            m1 &= m1 - 1ull;
+            const uint32_t ng = min(64u, M.kd_ngroups - 64u * j);
+            const ObbLane o = obb_wide<true>(M.kd_gobb + 256u * (size_t)j, lane, cx, cy, cz, Ew, gx, gy, gz, hx, hy, hz);
+            const bool keep = lane < ng && !(o.pk > res) && !(j == j0 && lane == g0);
+            const unsigned long long m = __ballot(keep);
+            const uint32_t at = cnt + (uint32_t)__popcll(m & lt);
+            if (keep && at < CUBE_CAP) L[at] = 64u * j + lane;
+            cnt += (uint32_t)__popcll(m);
+        }
+    }
+    if (lane == 0u) {
+        L[0] = 64u * j0 + g0;
+        H[0] = make_float4(cx, cy, cz, __uint_as_float(cnt <= CUBE_CAP ? cnt : CUBE_NONE));
+        H[1] = make_float4(h[0], h[1], h[2], 0.f);
+        H[2] = make_float4(gx, gy, gz, 0.f);
+    }
 }
 
 // exact evaluation of one packet group for one lane (second phase of the approximate pass): the

@@ -143,6 +143,11 @@ struct QueryWs {
                                    // [3] packets handed to the cooperative kernel, [4..7] its CoopDesc
     uint32_t* coop_list = nullptr;   // [COOP_CAP] (null in the static scratch: no cooperative kernel there)
     uint32_t* coop_state = nullptr;  // [COOP_CAP][7][64]
+    // cube lists of the running launch (k_cube_lists); none in the static scratch
+    float* cube_par = nullptr;
+    float4* cube_hdr = nullptr;
+    uint32_t* cube_list = nullptr;
+    size_t cubes_cap = 0;
     int64_t q_cap = 0, fb_cap = 0;
     RadixSorter sorter;
     bool fixed = false;  // carved out of the static scratch array: never grown, never freed
@@ -171,6 +176,7 @@ struct sdfhip_ctx {
     float4* d_kd_pn = nullptr;
     uint32_t* d_kd_gref = nullptr;  // packet groups in position order (refs)
     float4* d_kd_gobb = nullptr;    // their oriented boxes, [n_l1][4][64]
+    float4* d_kd_gobb_aos = nullptr;  // the same records, 64 B per group in group order (cube lists gather from it)
     float4* d_kd_l1obb = nullptr;   // boxes of the runs of 64 groups, [rows][4][64]
     size_t kd_groups_cap = 0;
     uint32_t n_groups = 0, n_l1 = 0;
@@ -199,6 +205,9 @@ struct sdfhip_ctx {
     int64_t opt_coop_max = 1 << 27;  // launches of more points than this keep their long waves (default: none does)
     int64_t opt_scan_max = -1;  // n x positions up to which a batch is answered by the exact scan; -1 = automatic
     int64_t opt_packet = 1;
+    int64_t opt_cube_lists = -1;   // packet pass, cube lists: -1 automatic (launches of >= opt_cube_min points), 0 off, 1 on
+    int64_t opt_cube_min = 8 << 20;
+    int64_t opt_cube_level = 0;    // cubes per axis = 2^level; 0 automatic (~4096 queries per cube)
     int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
     bool approx_ok = false;   // decided by every update(): see approx_pays()
     int64_t opt_packet_group = 0;  // vertices per packet group: 0 automatic (40 with the approximate pass, else 24)
@@ -606,6 +615,7 @@ int reserve_groups(sdfhip_ctx* h, uint32_t ngroups) {
         const size_t nl1 = (cap + 63) / 64, rows = (nl1 + 63) / 64;
         if (int rc = dalloc(&h->d_kd_gref, cap)) return rc;
         if (int rc = dalloc(&h->d_kd_gobb, 256 * nl1)) return rc;
+        if (int rc = dalloc(&h->d_kd_gobb_aos, 256 * nl1)) return rc;
         if (int rc = dalloc(&h->d_kd_l1obb, 256 * rows)) return rc;
         // lanes past the last child read (and ignore) what lies there: keep it defined
         HIPC(hipMemsetAsync(h->d_kd_gobb, 0, sizeof(float4) * 256 * nl1, h->stream));
@@ -619,7 +629,8 @@ int build_obbs(sdfhip_ctx* h, uint32_t ngroups) {
     h->n_groups = ngroups;
     h->n_l1 = (ngroups + 63u) / 64u;
     if (ngroups == 0) return 0;
-    k_group_obb<<<(ngroups + 63) / 64, 64, 0, s>>>(h->d_kd_gref, ngroups, h->d_kd_pts4, h->d_kd_vind, h->d_kd_gobb);
+    k_group_obb<<<(ngroups + 63) / 64, 64, 0, s>>>(h->d_kd_gref, ngroups, h->d_kd_pts4, h->d_kd_vind, h->d_kd_gobb,
+                                                   h->d_kd_gobb_aos);
     k_l1_obb<<<h->n_l1, 64, 0, s>>>(h->d_kd_gref, ngroups, h->d_kd_pts4, h->d_kd_vind, h->d_kd_l1obb);
     HIPC(hipGetLastError());
     return 0;
@@ -949,6 +960,8 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.kd_pn = h->d_kd_pn;
     M.kd_split = h->d_kd_split;
     M.kd_gobb = h->d_kd_gobb;
+    M.kd_gobb_aos = h->d_kd_gobb_aos;
+    M.cube_nc = 0u, M.cube_par = nullptr, M.cube_hdr = nullptr, M.cube_list = nullptr;  // (set per launch, run_query_t)
     M.kd_l1obb = h->d_kd_l1obb;
     M.kd_ngroups = h->n_groups;
     M.kd_nl1 = h->n_l1;
@@ -1271,6 +1284,28 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
                               m <= h->opt_coop_max;
             MeshDev Mm = M;  // the main kernel's view: its budget, and in the low bit who takes over beyond it
             Mm.heavy_budget = coop ? (M.coop_budget | 1u) : (M.heavy_budget & ~1u);
+            // Cube lists (kernels_packet.h, k_cube_lists): the sorted launch's query domain is cut into nc^3 cubes of
+            // ~4096 queries; one wave per cube lists the groups its queries can need and the packet waves test that
+            // list instead of walking the boxes from the top.  It pays when a cube is small against the mesh (short
+            // lists) and holds many waves: large launches.  Needs the launch's bounds (k_bounds), i.e. a sorted launch.
+            const bool lists = perm && !W.fixed && M.kd_ngroups != 0u &&
+                               (h->opt_cube_lists < 0 ? m >= h->opt_cube_min : h->opt_cube_lists != 0);
+            if (lists) {
+                int level = (int)h->opt_cube_level;
+                if (level <= 0) level = (int)std::lround(std::log2((double)m / 4096.0) / 3.0);
+                level = level < 1 ? 1 : (level > 6 ? 6 : level);
+                const uint32_t nc = 1u << level;
+                const size_t ncubes = (size_t)nc * nc * nc;
+                if (ncubes > W.cubes_cap) {
+                    if (!W.cube_par)
+                        if (int rc = dalloc(&W.cube_par, 8)) return rc;
+                    if (int rc = dalloc(&W.cube_hdr, 3 * ncubes)) return rc;
+                    if (int rc = dalloc(&W.cube_list, (size_t)CUBE_CAP * ncubes)) return rc;
+                    W.cubes_cap = ncubes;
+                }
+                k_cube_lists<<<(uint32_t)ncubes, 64, 0, s>>>(M, W.qbounds, nc, W.cube_par, W.cube_hdr, W.cube_list);
+                Mm.cube_nc = nc, Mm.cube_par = W.cube_par, Mm.cube_hdr = W.cube_hdr, Mm.cube_list = W.cube_list;
+            }
             if (approx)
                 k_query_packet<PK, ROBUST, true><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, 0, s>>>(
                     Mm, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
@@ -1695,6 +1730,14 @@ static int create_impl(const float* verts, uint32_t nv, const uint32_t* faces, u
         const long long v = atoll(e);
         h->opt_approx = v < 0 ? -1 : (v ? 1 : 0);
     }
+    if (const char* e = getenv("SDFHIP_CUBE_LISTS")) {  // default of option "cube_lists" (tests run the suite with the lists forced)
+        const long long v = atoll(e);
+        h->opt_cube_lists = v < 0 ? -1 : (v ? 1 : 0);
+    }
+    if (const char* e = getenv("SDFHIP_CUBE_LEVEL")) {
+        const long long v = atoll(e);
+        h->opt_cube_level = v < 0 ? 0 : (v > 6 ? 6 : v);
+    }
     if (const char* e = getenv("SDFHIP_COOP_BUDGET")) {  // default of option "coop_budget" (tuning: internal handles too)
         const long long v = atoll(e);
         h->opt_coop_budget = v < 0 ? 0 : v;
@@ -1799,7 +1842,8 @@ void sdfhip_destroy(sdfhip_t* h) {
         if (h->query_pending) (void)hipEventSynchronize(h->ev_query);  // a caller-stream query may still run
         (void)hipEventDestroy(h->ev_query);
     }
-    void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_gref, h->d_kd_gobb, h->d_kd_l1obb, h->d_kd_vind, h->d_adj_off,
+    void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_gref, h->d_kd_gobb, h->d_kd_gobb_aos, h->d_kd_l1obb,
+                    h->ws.cube_par, h->ws.cube_hdr, h->ws.cube_list, h->d_kd_vind, h->d_adj_off,
                     h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
@@ -2081,6 +2125,11 @@ int sdfhip_debug_ray_stats(unsigned long long out[8], int reset) {
     }
     return 0;
 }
+// tuning build: the cube tables of the handle's last launch (device pointers; header = 3 float4 per cube)
+int sdfhip_debug_cube_tables(sdfhip_t* h, void** hdr, void** list, unsigned long long* ncubes_cap) {
+    *hdr = h->ws.cube_hdr, *list = h->ws.cube_list, *ncubes_cap = h->ws.cubes_cap;
+    return 0;
+}
 int sdfhip_debug_packet_stats(unsigned long long out[12], int reset) {
     HIPC(hipDeviceSynchronize());
     HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_stats), 12 * sizeof(unsigned long long)));
@@ -2122,6 +2171,15 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_packet = v;
     else if (!strcmp(key, "approx"))
         h->opt_approx = v < 0 ? -1 : (v ? 1 : 0);
+    else if (!strcmp(key, "cube_lists"))
+        h->opt_cube_lists = v < 0 ? -1 : (v ? 1 : 0);
+    else if (!strcmp(key, "cube_min")) {
+        if (v < 0) return fail(SDFHIP_E_INVALID, "cube_min must be >= 0");
+        h->opt_cube_min = v;
+    } else if (!strcmp(key, "cube_level")) {
+        if (v < 0 || v > 6) return fail(SDFHIP_E_INVALID, "cube_level must be 0 (automatic) or in [1, 6]");
+        h->opt_cube_level = v;
+    }
     else if (!strcmp(key, "scan_max"))
         h->opt_scan_max = v < 0 ? -1 : v;
     else if (!strcmp(key, "heavy_budget")) {
