@@ -307,7 +307,12 @@ int sdfhip_host_free(void* p);
  * update: the x+ tie-break ray reads its own column grid over (y', z') instead of walking the LBVH), "column_sort" (0/1: robust
  * contains() sorts its queries by column of the ray-cast frame instead of 3-D Morton order), "coop_budget" (work units after
  * which a packet's walk is continued by eight waves, 0 = never; default 1500), "coop_max" (largest launch, in points, that
- * uses it; default 2^27 = every launch).  No option changes a result, except "fast_nn" as described. */
+ * uses it; default 2^27 = every launch), "cube_lists" (packet pass: the query domain of a sorted launch is cut into cubes, one
+ * wave per cube lists the vertex groups its queries can need and the packet waves test that list instead of walking the box
+ * hierarchy from the top; -1 automatic (default: launches of >= "cube_min" points, default 2^23), 0 off, 1 on for every sorted
+ * launch), "cube_level" (2^level cubes per axis; 0 = automatic, default: cube edge ~1.3 x the size of a vertex group),
+ * "sort_bits" (Morton key bits of the query sort: 24 (default, three radix passes) or 30 (four)).
+ * No option changes a result, except "fast_nn" as described. */
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t value);
 
 const char* sdfhip_last_error(void);

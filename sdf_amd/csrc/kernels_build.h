@@ -156,7 +156,7 @@ struct ColumnKey {
 // tile's digit histogram of the first sort pass (what k_rs_hist would read the keys again for).
 __global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __restrict__ pts, uint32_t n,
                                                              const uint32_t* __restrict__ b, uint32_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ hist, uint32_t ntiles, ColumnKey CK) {
+                                                             uint32_t* __restrict__ hist, uint32_t ntiles, ColumnKey CK, int key_shift) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     float lo[3] = {0.f, 0.f, 0.f}, inv[3] = {0.f, 0.f, 0.f};
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __rest
                 const float fy = fminf(fmaxf((yr - CK.o1) * CK.s1, 0.f), 4095.f);
                 key = expand16((uint32_t)fx) | (expand16((uint32_t)fy) << 1);
             } else {
-                key = morton30(x[k], y[k], z[k], lo, inv) >> 6;
+                key = morton30(x[k], y[k], z[k], lo, inv) >> key_shift;
             }
             keys[i] = key;
             atomicAdd(&h[key & 255u], 1u);

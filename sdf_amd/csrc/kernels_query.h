@@ -23,10 +23,10 @@ struct MeshDev {
     const float4* kd_l1obb;  // [ceil(kd_nl1 / 64)][4][64]
     uint32_t kd_ngroups, kd_nl1;
     const float4* kd_gobb_aos;  // the group boxes once more, 64 B per group in group order (gathered through the cube lists)
-    // cube lists of the running launch (k_cube_lists; cube_nc == 0: none): the query domain is cut into cube_nc^3
-    // cubes and each cube lists the packet groups any query inside it can need
-    uint32_t cube_nc;
-    const float* cube_par;      // {lo.xyz, cubes per unit length .xyz}: a query's cube
+    // cube lists of the running launch (k_cube_lists; cube_max == 0: none): the query domain is cut into cubes
+    // (at most cube_max) and each cube lists the packet groups any query inside it can need
+    uint32_t cube_max;
+    const float* cube_par;      // {lo.xyz, cubes per unit length .xyz, cubes per axis .xyz}: a query's cube
     const float4* cube_hdr;     // [cube][3]: {centre.xyz, entries}, {half extents.xyz, -}, {trend direction g.xyz, -}
     const uint32_t* cube_list;  // [cube][CUBE_CAP] group indices; entry 0 is the group every wave evaluates first
     float obb_cm[3], obb_rm;  // centre of the mesh AABB, sum of its extents (rounding slack of the box tests)

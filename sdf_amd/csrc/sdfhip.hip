@@ -251,6 +251,7 @@ struct sdfhip_ctx {
     size_t gstack_words = 0;
     // options
     int64_t opt_sort = 1, opt_sort_min = 8192, opt_chunk = 1 << 27;
+    int64_t opt_sort_bits = 24;  // Morton key bits of the query sort (24: three radix passes, 30: four)
     int64_t opt_sort_min_contains = -1;  // robust contains(): -1 automatic, see run_query_t
     int64_t opt_column_sort = 1;  // robust contains(): sort by column of the ray-cast frame (0: 3-D Morton order)
     hipStream_t stream = nullptr;  // internal stream for create/update and host entry points
@@ -961,7 +962,7 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.kd_split = h->d_kd_split;
     M.kd_gobb = h->d_kd_gobb;
     M.kd_gobb_aos = h->d_kd_gobb_aos;
-    M.cube_nc = 0u, M.cube_par = nullptr, M.cube_hdr = nullptr, M.cube_list = nullptr;  // (set per launch, run_query_t)
+    M.cube_max = 0u, M.cube_par = nullptr, M.cube_hdr = nullptr, M.cube_list = nullptr;  // (set per launch, run_query_t)
     M.kd_l1obb = h->d_kd_l1obb;
     M.kd_ngroups = h->n_groups;
     M.kd_nl1 = h->n_l1;
@@ -1259,9 +1260,10 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             }
             if (int rc = W.sorter.reserve((uint32_t)m)) return rc;  // (the key kernel fills its first histogram)
             const uint32_t ntiles = (uint32_t)((m + RS_TILE - 1) / RS_TILE);
-            k_query_morton<<<ntiles, RS_THREADS, 0, s>>>(p, (uint32_t)m, W.qbounds, W.qkeys, W.sorter.hist, ntiles, CK);
+            const int key_bits = CK.on ? 24 : (int)h->opt_sort_bits;
+            k_query_morton<<<ntiles, RS_THREADS, 0, s>>>(p, (uint32_t)m, W.qbounds, W.qkeys, W.sorter.hist, ntiles, CK, 30 - key_bits);
             uint32_t* sorted_perm = nullptr;
-            if (int rc = W.sorter.sort(W.qkeys, W.qperm, (uint32_t)m, 24, 1, s, nullptr, &sorted_perm, false, true))
+            if (int rc = W.sorter.sort(W.qkeys, W.qperm, (uint32_t)m, key_bits, 1, s, nullptr, &sorted_perm, false, true))
                 return rc;
             perm = sorted_perm;
         }
@@ -1291,20 +1293,27 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             const bool lists = perm && !W.fixed && M.kd_ngroups != 0u &&
                                (h->opt_cube_lists < 0 ? m >= h->opt_cube_min : h->opt_cube_lists != 0);
             if (lists) {
-                int level = (int)h->opt_cube_level;
-                if (level <= 0) level = (int)std::lround(std::log2((double)m / 4096.0) / 3.0);
-                level = level < 1 ? 1 : (level > 6 ? 6 : level);
-                const uint32_t nc = 1u << level;
-                const size_t ncubes = (size_t)nc * nc * nc;
+                // cube edge: ~1.3 x the size of a packet group, estimated from the surface of the mesh AABB (as
+                // approx_window does); the device lays the grid out over the launch's bounds (k_cube_lists)
+                double ex[3], area;
+                for (int d = 0; d < 3; ++d) ex[d] = (double)h->aabb[d + 3] - (double)h->aabb[d];
+                area = 2.0 * (ex[0] * ex[1] + ex[1] * ex[2] + ex[2] * ex[0]);
+                double side = 1.3 * std::sqrt(area / (double)M.kd_ngroups);
+                if (!(side > 0.0) || !std::isfinite(side)) side = 1.3 * std::fmax(ex[0], std::fmax(ex[1], ex[2])) / std::cbrt((double)M.kd_ngroups);
+                if (!(side > 0.0) || !std::isfinite(side)) side = 1.0;
+                const uint32_t level = (uint32_t)(h->opt_cube_level > 0 ? h->opt_cube_level : 0);
+                // at most one cube per 256 queries (a cube must hold several waves to pay for its list)
+                size_t ncubes = level ? (size_t)1 << (3 * level) : (size_t)std::min<int64_t>(std::max<int64_t>(m / 256, 64), 1 << 18);
                 if (ncubes > W.cubes_cap) {
                     if (!W.cube_par)
-                        if (int rc = dalloc(&W.cube_par, 8)) return rc;
+                        if (int rc = dalloc(&W.cube_par, 16)) return rc;
                     if (int rc = dalloc(&W.cube_hdr, 3 * ncubes)) return rc;
                     if (int rc = dalloc(&W.cube_list, (size_t)CUBE_CAP * ncubes)) return rc;
                     W.cubes_cap = ncubes;
                 }
-                k_cube_lists<<<(uint32_t)ncubes, 64, 0, s>>>(M, W.qbounds, nc, W.cube_par, W.cube_hdr, W.cube_list);
-                Mm.cube_nc = nc, Mm.cube_par = W.cube_par, Mm.cube_hdr = W.cube_hdr, Mm.cube_list = W.cube_list;
+                k_cube_lists<<<(uint32_t)ncubes, 64, 0, s>>>(M, W.qbounds, (float)side, level, (uint32_t)ncubes, W.cube_par,
+                                                              W.cube_hdr, W.cube_list);
+                Mm.cube_max = (uint32_t)ncubes, Mm.cube_par = W.cube_par, Mm.cube_hdr = W.cube_hdr, Mm.cube_list = W.cube_list;
             }
             if (approx)
                 k_query_packet<PK, ROBUST, true><<<(uint32_t)((m + PBLOCK - 1) / PBLOCK), PBLOCK, 0, s>>>(
@@ -2126,8 +2135,10 @@ int sdfhip_debug_ray_stats(unsigned long long out[8], int reset) {
     return 0;
 }
 // tuning build: the cube tables of the handle's last launch (device pointers; header = 3 float4 per cube)
-int sdfhip_debug_cube_tables(sdfhip_t* h, void** hdr, void** list, unsigned long long* ncubes_cap) {
-    *hdr = h->ws.cube_hdr, *list = h->ws.cube_list, *ncubes_cap = h->ws.cubes_cap;
+int sdfhip_debug_cube_tables(sdfhip_t* h, void** hdr, void** list, unsigned long long* ncubes) {
+    uint32_t par[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (h->ws.cube_par) HIPC(hipMemcpy(par, h->ws.cube_par, sizeof(par), hipMemcpyDeviceToHost));
+    *hdr = h->ws.cube_hdr, *list = h->ws.cube_list, *ncubes = (unsigned long long)par[6] * par[7] * par[8];
     return 0;
 }
 int sdfhip_debug_packet_stats(unsigned long long out[12], int reset) {
@@ -2218,7 +2229,10 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_packet_group = v;
     } else if (!strcmp(key, "sort_min"))
         h->opt_sort_min = v;
-    else if (!strcmp(key, "sort_min_contains"))
+    else if (!strcmp(key, "sort_bits")) {
+        if (v != 24 && v != 30) return fail(SDFHIP_E_INVALID, "sort_bits must be 24 or 30");
+        h->opt_sort_bits = v;
+    } else if (!strcmp(key, "sort_min_contains"))
         h->opt_sort_min_contains = v;
     else if (!strcmp(key, "column_sort"))
         h->opt_column_sort = v ? 1 : 0;

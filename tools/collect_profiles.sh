@@ -11,10 +11,10 @@ mkdir -p $OUT
 REPO=$PWD
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-grid"
+BENCH="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-grid --no-c5"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1 || exit 2
 cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv
-P1="python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-grid"
+P1="python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-grid --no-c5"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o p -- $P1 > $OUT/pf.log 2>&1 || exit 3
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pw -o p -- $P1 > $OUT/pw.log 2>&1 || exit 4
 timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $OUT/pt -o p -- $P1 > $OUT/pt.log 2>&1 || exit 5
