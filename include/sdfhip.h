@@ -306,7 +306,7 @@ int sdfhip_host_free(void* p);
  * grid's cells), "grid_per_face" (list entries per face beyond which the grid coarsens), "x_grid" (0/1, applies at the next
  * update: the x+ tie-break ray reads its own column grid over (y', z') instead of walking the LBVH), "column_sort" (0/1: robust
  * contains() sorts its queries by column of the ray-cast frame instead of 3-D Morton order), "coop_budget" (work units after
- * which a packet's walk is continued by eight waves, 0 = never; default 1500), "coop_max" (largest launch, in points, that
+ * which a packet's walk is continued by eight waves, 0 = never; default -1 = automatic: 1500, less for launches of < 1M points), "coop_max" (largest launch, in points, that
  * uses it; default 2^27 = every launch), "cube_lists" (packet pass: the query domain of a sorted launch is cut into cubes, one
  * wave per cube lists the vertex groups its queries can need and the packet waves test that list instead of walking the box
  * hierarchy from the top; -1 automatic (default: launches of >= "cube_min" points, default 2^23), 0 off, 1 on for every sorted

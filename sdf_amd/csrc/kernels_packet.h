@@ -1192,8 +1192,9 @@ __global__ void k_fb_compact(const unsigned long long* __restrict__ amb_mask,
 // decision: window test, path check, else defer to the strict kernel's list.
 // pos_out != nullptr (scan mode, kinds with a tail): the tree position (-1 none, -2 deferred) is
 // stored per query and k_scan_finish does ray parity + face distances one lane per query.
-constexpr int HEAVY_Q = 4;
-template <int KIND, bool ROBUST, int WAVES>
+constexpr int HEAVY_Q_DEFAULT = 4;
+constexpr int HEAVY_Q = HEAVY_Q_DEFAULT;  // (host side: queries per block of the default instantiation)
+template <int KIND, bool ROBUST, int WAVES, int HEAVY_Q = HEAVY_Q_DEFAULT>
 __global__ __launch_bounds__(64 * WAVES) void k_query_heavy(MeshDev M, const float* __restrict__ pts,
                                                             const uint32_t* __restrict__ heavy_list,
                                                             const uint32_t* __restrict__ heavy_cnt,
@@ -1332,8 +1333,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_query_heavy(MeshDev M, const flo
             if (pos < 0) amb = true;
         }
         if (amb) fb_list[atomicAdd(fb_cnt, 1u)] = msrc;
-        if (pos_out) {
-            pos_out[msrc] = amb ? -2 : pos;
+        if (pos_out) {  // per slot of the list (scan mode: slot == query)
+            pos_out[q0 + threadIdx.x] = amb ? -2 : pos;
         } else if (amb) {
         } else if (KIND == Q_NN) {
             ((int32_t*)out)[msrc] = pos >= 0 ? M.kd_vind[pos] : -1;
@@ -1351,14 +1352,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_query_heavy(MeshDev M, const flo
 }
 
 // scan mode, kinds with a tail: ray parity + incident-face distances, one lane per query
+// list != nullptr: slot s of pos_in belongs to query list[s], *cnt_dev slots (nothing to do beyond n of them:
+// longer lists were finished inside k_query_heavy)
 template <int KIND, bool ROBUST>
 __global__ __launch_bounds__(256) void k_scan_finish(MeshDev M, const float* __restrict__ pts,
                                                      const int32_t* __restrict__ pos_in, uint32_t n,
-                                                     int trunc_aabb, void* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int pos = pos_in[i];
+                                                     int trunc_aabb, void* __restrict__ out,
+                                                     const uint32_t* __restrict__ list = nullptr,
+                                                     const uint32_t* __restrict__ cnt_dev = nullptr) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cnt_dev && *cnt_dev > n) return;
+    if (slot >= (cnt_dev ? *cnt_dev : n)) return;
+    const int pos = pos_in[slot];
     if (pos == -2) return;  // deferred: the strict kernel answers it
+    const uint32_t i = list ? list[slot] : slot;
     const V3 p = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
     if (KIND == Q_NN) {
         ((int32_t*)out)[i] = pos >= 0 ? M.kd_vind[pos] : -1;

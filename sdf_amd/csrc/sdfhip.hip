@@ -130,6 +130,7 @@ struct GridBuf {
 
 // Device workspace of one query call: Morton keys / permutation of the query sort (+ the sorter's
 // alternates and histograms), the per-wave masks of deferred queries, the deferred / heavy lists.
+constexpr uint32_t HEAVY_SHORT = 8192;  // heavy lists up to this length: the many-waves-per-query scan + k_scan_finish
 struct QueryWs {
     uint32_t* qkeys = nullptr;
     uint32_t* qperm = nullptr;
@@ -141,6 +142,7 @@ struct QueryWs {
     uint32_t* fb_list = nullptr;   // [0, cap): deferred near-tie queries; [cap, 2 cap): heavy-wave queries
     uint32_t* fb_count = nullptr;  // [0], [1] length of the deferred list (ping-pong, see k_fb_compact), [2] heavy list,
                                    // [3] packets handed to the cooperative kernel, [4..7] its CoopDesc
+    int32_t* heavy_pos = nullptr;    // [HEAVY_SHORT] tree positions of a short heavy list (k_scan_finish)
     uint32_t* coop_list = nullptr;   // [COOP_CAP] (null in the static scratch: no cooperative kernel there)
     uint32_t* coop_state = nullptr;  // [COOP_CAP][7][64]
     // cube lists of the running launch (k_cube_lists); none in the static scratch
@@ -201,7 +203,8 @@ struct sdfhip_ctx {
     uint32_t* h_counts = nullptr;  // page-locked: [0] length of the last deferred list, [1] queries of the
                                    // last call's heavy waves (read back only while profiling)
     int64_t opt_heavy_budget = 0;  // chunks per wave before it gives up; 0 = automatic
-    int64_t opt_coop_budget = 1500;  // work units after which a packet goes on in the cooperative kernel; 0 = never
+    int64_t opt_coop_budget = -1;  // work units after which a packet goes on in the cooperative kernel; 0 = never,
+                                   // -1 = automatic: 1500, less for launches of < 1M points (see run_query_t)
     int64_t opt_coop_max = 1 << 27;  // launches of more points than this keep their long waves (default: none does)
     int64_t opt_scan_max = -1;  // n x positions up to which a batch is answered by the exact scan; -1 = automatic
     int64_t opt_packet = 1;
@@ -330,6 +333,7 @@ int scratch_carve(unsigned char* base, QueryWs* W) {
     W->amb_s2 = (uint32_t*)take(4 * (nw / 2048 / 2048 + 4));
     W->qbounds = (uint32_t*)take(4 * 8);
     W->fb_count = (uint32_t*)take(4 * 8);
+    W->heavy_pos = (int32_t*)take(4 * (HEAVY_SHORT + 64));
     W->q_cap = W->fb_cap = (int64_t)n;
     W->fixed = true;
     if (off > SCRATCH_BYTES) return fail(SDFHIP_E_STATE, "static scratch too small (%zu > %zu bytes)", off, SCRATCH_BYTES);
@@ -985,7 +989,7 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     // a wave may walk 1/8 of the tree (4 positions per chunk) before it hands its queries over
     M.heavy_budget = h->opt_heavy_budget > 0 ? (uint32_t)h->opt_heavy_budget
                                              : (M.kd_npos / 32u > 4096u ? M.kd_npos / 32u : 4096u);
-    M.coop_budget = (uint32_t)std::min<int64_t>(h->opt_coop_budget, M.heavy_budget);
+    M.coop_budget = (uint32_t)std::min<int64_t>(h->opt_coop_budget < 0 ? 1500 : h->opt_coop_budget, M.heavy_budget);
     M.amb_c = h->amb_c;
     M.vmax2 = h->vmax2;
     M.amb_c2 = h->amb_c2;
@@ -1198,7 +1202,6 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             // 125M sdf step 20.73 -> 20.5 ms with 8).  A long
             // one (41k of 64M on the smooth icosphere-7) is throughput bound and 4-wave blocks are faster
             // (sdf 22.3 against 24.5 ms).  Both variants are launched; each returns at once outside its range.
-            constexpr uint32_t HEAVY_SHORT = 8192;
             // A very long list is not the near-symmetry kind: the batch is spread over a region much larger than
             // the mesh and whole packets, as wide as the mesh, were sent here unwalked (packet_walk).  The scan
             // costs a pass over every vertex per query (8M points in a box 300 x the mesh: 554 ms); the strict
@@ -1206,10 +1209,26 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             // has a floor of several ms.  Above heavy_strict queries the strict kernel takes the list (strict mode only).
             const double hs = 4.0e10 / (double)(M.kd_npos ? M.kd_npos : 1u);
             const uint32_t heavy_strict = fast ? 0xFFFFFFFFu : (uint32_t)(hs < 65536.0 ? 65536.0 : (hs > 4.0e9 ? 4.0e9 : hs));
-            const int64_t g16 = packs < HEAVY_SHORT / HEAVY_Q ? packs : HEAVY_SHORT / HEAVY_Q;
-            k_query_heavy<HK, ROBUST, 8><<<(uint32_t)g16, 512, 0, s>>>(
+            // short lists: SHORT_Q queries per block of SHORT_W waves, one round of blocks on the GPU (2.3k queries are
+            // 289 blocks; with 4 queries per block of 8 waves they were 577: two rounds of 512).  Kinds with a tail
+            // store the tree position per list slot and k_scan_finish does ray parity + face distances one lane per
+            // query — inside the scan kernel four threads of a block did that, one dependent load after the other,
+            // while the other 508 waited (sdf 125M: 0.42 ms against nn's 0.19).
+#ifndef SDFK_SHORT_W
+#define SDFK_SHORT_W 8
+#endif
+#ifndef SDFK_SHORT_Q
+#define SDFK_SHORT_Q 4
+#endif
+            constexpr int SHORT_W = SDFK_SHORT_W, SHORT_Q = SDFK_SHORT_Q;
+            const int64_t packs_s = (std::min<int64_t>(deferred_pts, HEAVY_SHORT) + SHORT_Q - 1) / SHORT_Q;
+            int32_t* spos = (KIND == Q_NN) ? nullptr : W.heavy_pos;
+            k_query_heavy<HK, ROBUST, SHORT_W, SHORT_Q><<<(uint32_t)packs_s, 64 * SHORT_W, 0, s>>>(
                 M, d_pts, W.fb_list + W.fb_cap, W.fb_count + 2, trunc, d_out, W.fb_list,
-                W.fb_count + flip, 0u, nullptr, 1u, HEAVY_SHORT);
+                W.fb_count + flip, 0u, spos, 1u, HEAVY_SHORT);
+            if (spos)
+                k_scan_finish<HK, ROBUST><<<HEAVY_SHORT / 256, 256, 0, s>>>(M, d_pts, spos, HEAVY_SHORT, trunc, d_out,
+                                                                            W.fb_list + W.fb_cap, W.fb_count + 2);
             if (deferred_pts > (int64_t)HEAVY_SHORT)
                 k_query_heavy<HK, ROBUST, 4><<<(uint32_t)(packs < 8192 ? packs : 8192), 256, 0, s>>>(
                     M, d_pts, W.fb_list + W.fb_cap, W.fb_count + 2, trunc, d_out, W.fb_list,
@@ -1284,8 +1303,16 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             // (125M sdf 22.22 -> 21.93 ms, icosphere-7 64M 14.0 -> 13.55 ms).
             const bool coop = approx && M.coop_budget != 0u && W.coop_list && !(ROBUST && KIND == Q_CONTAINS) &&
                               m <= h->opt_coop_max;
+            // Hand-over budget.  The main launch cannot end before its longest wave does, and a wave's walk is a chain
+            // of dependent loads (~0.35 us per work unit when the GPU is nearly empty): a small launch is as long as
+            // its budget.  Automatic: 1500 units from 1M points on (tools/budget_sweep.sh), proportionally less below,
+            // not under 300 (100k points: nn 1.16 -> 0.95 ms; the cooperative kernel takes the packets over earlier —
+            // few of them in a small launch, far from its capacity COOP_CAP).
+            uint32_t coop_budget = M.coop_budget;
+            if (h->opt_coop_budget < 0 && m < (1ll << 20))
+                coop_budget = std::min<uint32_t>(coop_budget, (uint32_t)std::max<int64_t>(300, 1500 * m >> 20));
             MeshDev Mm = M;  // the main kernel's view: its budget, and in the low bit who takes over beyond it
-            Mm.heavy_budget = coop ? (M.coop_budget | 1u) : (M.heavy_budget & ~1u);
+            Mm.heavy_budget = coop ? (coop_budget | 1u) : (M.heavy_budget & ~1u);
             // Cube lists (kernels_packet.h, k_cube_lists): the sorted launch's query domain is cut into nc^3 cubes of
             // ~4096 queries; one wave per cube lists the groups its queries can need and the packet waves test that
             // list instead of walking the boxes from the top.  It pays when a cube is small against the mesh (short
@@ -1749,7 +1776,7 @@ static int create_impl(const float* verts, uint32_t nv, const uint32_t* faces, u
     }
     if (const char* e = getenv("SDFHIP_COOP_BUDGET")) {  // default of option "coop_budget" (tuning: internal handles too)
         const long long v = atoll(e);
-        h->opt_coop_budget = v < 0 ? 0 : v;
+        h->opt_coop_budget = v < 0 ? -1 : v;
     }
     if (const char* e = getenv("SDFHIP_SCAN_MAX")) {  // default of option "scan_max" (tests pin the tree paths with 0)
         const long long v = atoll(e);
@@ -1790,6 +1817,7 @@ static int create_impl(const float* verts, uint32_t nv, const uint32_t* faces, u
     A(dalloc(&h->d_verts, 3 * (size_t)nv));
     A(dalloc(&h->d_faces, 3 * (size_t)nf));
     A(dalloc(&h->ws.fb_count, 8));
+    A(dalloc(&h->ws.heavy_pos, HEAVY_SHORT + 64));
     A(dalloc(&h->d_adj_off, (size_t)nv + 1));
     A(dalloc(&h->d_adj_faces, 3 * (size_t)nf));
     A(dalloc(&h->d_geo, 4 * (size_t)nf));
@@ -1857,7 +1885,7 @@ void sdfhip_destroy(sdfhip_t* h) {
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
                     h->topo.depthI, h->ws.qkeys, h->ws.qperm, h->ws.qbounds, h->d_gstack, h->d_kd_pts4, h->d_kd_apx4, h->d_kd_lbox,
-                    h->ws.fb_list, h->ws.fb_count, h->ws.coop_list, h->ws.coop_state, h->ws.amb_mask, h->ws.amb_cnt, h->ws.amb_s1, h->ws.amb_s2,
+                    h->ws.fb_list, h->ws.fb_count, h->ws.heavy_pos, h->ws.coop_list, h->ws.coop_state, h->ws.amb_mask, h->ws.amb_cnt, h->ws.amb_s1, h->ws.amb_s2,
                     h->d_vkeys, h->d_vidx};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -2197,7 +2225,7 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         if (v < 0 || v > 0x7FFFFFFF) return fail(SDFHIP_E_INVALID, "heavy_budget must be >= 0 (0 = automatic)");
         h->opt_heavy_budget = v;
     } else if (!strcmp(key, "coop_budget")) {
-        if (v < 0 || v > 0x7FFFFFFF) return fail(SDFHIP_E_INVALID, "coop_budget must be >= 0 (0 = no cooperative kernel)");
+        if (v < -1 || v > 0x7FFFFFFF) return fail(SDFHIP_E_INVALID, "coop_budget must be >= -1 (0 = no cooperative kernel, -1 = automatic)");
         h->opt_coop_budget = v;
     } else if (!strcmp(key, "coop_max")) {
         if (v < 0) return fail(SDFHIP_E_INVALID, "coop_max must be >= 0");
