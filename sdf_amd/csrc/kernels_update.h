@@ -149,3 +149,11 @@ __global__ void k_face_precompute(const float* __restrict__ verts, const uint32_
         fbox[6 * (size_t)f + 3] = mx.x, fbox[6 * (size_t)f + 4] = mx.y, fbox[6 * (size_t)f + 5] = mx.z;
     }
 }
+
+// geo records once more in vertex-major order (calc_tail reads a vertex's incident faces as one run)
+__global__ void k_geo_adj(const float4* __restrict__ geo, const int32_t* __restrict__ adj_faces, uint32_t n_adj,
+                          float4* __restrict__ geo_adj) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread
+    if (t >= 4u * n_adj) return;
+    geo_adj[t] = geo[4u * (size_t)adj_faces[t >> 2] + (t & 3u)];
+}

@@ -219,6 +219,7 @@ struct sdfhip_ctx {
     uint32_t* d_adj_off = nullptr;
     int32_t* d_adj_faces = nullptr;
     float4* d_geo = nullptr;
+    float4* d_geo_adj = nullptr;  // the same records per (vertex, incident face), 64 B x 3F
     float4* d_rface = nullptr;
     float* d_area_cum = nullptr;  // running sum of face areas (sample_surface), valid iff cum_valid
     bool cum_valid = false;
@@ -600,6 +601,8 @@ int update_device_side(sdfhip_ctx* h) {
         k_face_precompute<<<(h->nf + 255) / 256, 256, 0, s>>>(h->d_verts, h->d_faces, h->nf, R,
                                                                h->robust ? 1 : 0, h->d_geo, h->d_rface,
                                                                h->d_fbox, h->d_normals, h->d_areas);
+    if (h->nf)
+        k_geo_adj<<<(uint32_t)((12 * (size_t)h->nf + 255) / 256), 256, 0, s>>>(h->d_geo, h->d_adj_faces, 3u * h->nf, h->d_geo_adj);
     HIPC(hipGetLastError());
     h->h_face_valid = false;
     h->cum_valid = false;
@@ -996,6 +999,7 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.adj_off = h->d_adj_off;
     M.adj_faces = h->d_adj_faces;
     M.geo = h->d_geo;
+    M.geo_adj = h->d_geo_adj;
     M.rnodes = h->d_rnodes;
     M.n_rnodes = h->robust && h->lbvh_valid ? h->n_rnodes : 0;
     M.rface = h->d_rface;
@@ -1821,6 +1825,7 @@ static int create_impl(const float* verts, uint32_t nv, const uint32_t* faces, u
     A(dalloc(&h->d_adj_off, (size_t)nv + 1));
     A(dalloc(&h->d_adj_faces, 3 * (size_t)nf));
     A(dalloc(&h->d_geo, 4 * (size_t)nf));
+    A(dalloc(&h->d_geo_adj, 12 * (size_t)nf));
     A(dalloc(&h->d_normals, 3 * (size_t)nf));
     A(dalloc(&h->d_areas, (size_t)nf));
     A(dalloc(&h->d_rface, h->robust ? 3 * (size_t)nf : 1));
@@ -1881,7 +1886,7 @@ void sdfhip_destroy(sdfhip_t* h) {
     }
     void* ptrs[] = {h->d_verts, h->d_faces, h->d_kd_pn, h->d_kd_split, h->d_kd_gref, h->d_kd_gobb, h->d_kd_gobb_aos, h->d_kd_l1obb,
                     h->ws.cube_par, h->ws.cube_hdr, h->ws.cube_list, h->d_kd_vind, h->d_adj_off,
-                    h->d_adj_faces, h->d_geo, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
+                    h->d_adj_faces, h->d_geo, h->d_geo_adj, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
                     h->topo.depthI, h->ws.qkeys, h->ws.qperm, h->ws.qbounds, h->d_gstack, h->d_kd_pts4, h->d_kd_apx4, h->d_kd_lbox,
