@@ -990,7 +990,10 @@ __device__ __forceinline__ void packet_finish(const MeshDev& M, V3 p, bool valid
 // M.heavy_budget (odd: hand over to the cooperative kernel at that budget; the host sets it per launch),
 // the counter is the word after the heavy counter and the two pointers sit in device memory behind
 // it (CoopDesc at heavy_cnt + 2, written once by the host), read only by the waves that hand over.
-constexpr int COOP_WAVES = 8;
+#ifndef SDFK_COOP_WAVES
+#define SDFK_COOP_WAVES 8
+#endif
+constexpr int COOP_WAVES = SDFK_COOP_WAVES;
 constexpr uint32_t COOP_CAP = 16384;  // packets one launch can hand over (28 MiB of lists)
 struct CoopDesc {
     uint32_t* list;   // [COOP_CAP] packet (wave) index within the launch
