@@ -95,8 +95,6 @@ int follow_update(sdfhip_ctx* h, sdfhip_ctx* L, UpdateSync* sync) {
     if (sync)
         if (int rc = sync->wait(1)) return leader_failed(rc);
     std::memcpy(h->aabb, L->aabb, sizeof(h->aabb));
-    std::memcpy(h->apx_c, L->apx_c, sizeof(h->apx_c));
-    h->apx_centred = L->apx_centred;
     h->opt_fast_nn = L->opt_fast_nn;
     if (h->robust) std::memcpy(h->R, L->R, sizeof(h->R));  // (the leader's, as drawn or pinned for this update)
     if (sync) HIPC(hipStreamWaitEvent(s, sync->ev_verts, 0));
@@ -117,8 +115,8 @@ int follow_update(sdfhip_ctx* h, sdfhip_ctx* L, UpdateSync* sync) {
     // ---- stage 2: the built tree -----------------------------------------------------------------------
     if (sync)
         if (int rc = sync->wait(2)) return leader_failed(rc);
-    h->approx_ok = L->approx_ok;
-    h->amb_c = L->amb_c, h->amb_c2 = L->amb_c2, h->vmax2 = L->vmax2;
+    h->approx_ok = h->approx_pre = L->approx_pre;  // (fill_apx below finishes the decision as the leader's does)
+    h->amb_c = L->amb_c, h->amb_c2 = L->amb_c2;
     h->kd_depth = L->kd_depth, h->kd_root = L->kd_root, h->kd_npos = L->kd_npos, h->kd_nnodes = L->kd_nnodes;
     const uint32_t ngroups = L->n_groups;
     const size_t nalloc = (size_t)h->kd_npos + 16;
@@ -130,13 +128,12 @@ int follow_update(sdfhip_ctx* h, sdfhip_ctx* L, UpdateSync* sync) {
     HIPC(pull(h->d_kd_pn, L->d_kd_pn, sizeof(sdfk::KdNodeH) * (size_t)h->kd_nnodes));
     HIPC(pull(h->d_kd_split, L->d_kd_split, sizeof(uint32_t) * (size_t)h->kd_nnodes));
     HIPC(pull(h->d_kd_gref, L->d_kd_gref, sizeof(uint32_t) * (size_t)ngroups));
-    k_apx_fill<<<(uint32_t)((nalloc + 255) / 256), 256, 0, s>>>(h->d_kd_pts4, (uint32_t)nalloc, h->apx_c[0], h->apx_c[1],
-                                                               h->apx_c[2], h->d_kd_apx4);
     k_leaf_boxes<<<(h->kd_nnodes + 255) / 256 + (h->kd_nnodes == 0), 256, 0, s>>>(
         h->d_kd_pn, h->kd_nnodes, h->kd_root, h->aabb[0], h->aabb[1], h->aabb[2], h->aabb[3], h->aabb[4], h->aabb[5],
         h->d_kd_lbox);
     if (int rc = build_obbs(h, ngroups)) return rc;
-    HIPC(hipStreamSynchronize(s));  // (the leader may start its next update once every follower is through)
+    if (int rc = fill_apx(h, ngroups, nalloc)) return rc;  // (synchronizes: the leader may start its next update once
+                                                           // every follower is through)
     h->last_update_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }

@@ -312,15 +312,43 @@ __device__ __forceinline__ void group_exact(const MeshDev& M, float qx, float qy
     S.b = b, S.s2 = s2, S.h = h;
 }
 
+// Error model of the approximate pass's estimates (group-centred form, k_apx_fill).  With u = 2^-24, R >= |w| for
+// every stored w = fl(v - cg), t = fl(q - cg), d = |q - v|:  the estimate est = fl(a'' + Qg),
+// a'' = fma chain of W - 2 t.w, Qg = fma chain of |t|^2, differs from d^2 by
+//     2 d u (|t| + |w|)       roundings of t and w against the true q - cg, v - cg
+//   + 3 u |t|^2 + u |w|^2     roundings of Qg, of W
+//   + 3 u (2 |t||w| + |w|^2)  the three FMA roundings of a''
+//   + u est                   the final add
+// and with |t| <= d + R:  |est - d^2| <= u (6 d^2 + 16 d R + 13 R^2) <= u (14 d^2 + 21 R^2) (1 + small).  In terms of
+// the estimate itself: E(est) = u (16 max(est, 0) + 24 R^2) >= that (M.apx_k1 = 16 u, M.apx_e0 = 24 u R^2, rounded
+// up by the host).  The reference's own D(v) lies within 5.01 u of d^2, hence
+//     lower(est) = (est - E)(1 - 8u)  <=  D(v)  <=  (est + E)(1 + 8u) = upper(est).
+__device__ __forceinline__ float apx_err(const MeshDev& M, float est) {
+    return __builtin_fmaf(fmaxf(est, 0.f), M.apx_k1, M.apx_e0);
+}
+__device__ __forceinline__ float apx_upper(const MeshDev& M, float est) {  // (NaN / inf pass through: prune nothing)
+    const float x = est + apx_err(M, est);
+    return fmaxf(fmaxf(x * (1.f + 8.f * 5.9604645e-8f), x), 0.f);
+}
+__device__ __forceinline__ float apx_lower(const MeshDev& M, float est) {
+    const float y = est - apx_err(M, est);
+    return fminf(y * (1.f - 8.f * 5.9604645e-8f), y);
+}
+
 // approximate evaluation (see "Approximate first pass" below): group minimum of a(), sorted insert
 // DEDUPE (continuation of a walk by the cooperative kernel): a lane that already lists `cur` among its first
 // three groups keeps its list (the group was evaluated before the hand-over).
 template <bool DEDUPE>
-__device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y2, float Z2, uint32_t cur,
+__device__ __forceinline__ void group_approx(const MeshDev& M, float qx, float qy, float qz, uint32_t cur,
                                              ApproxState& S) {
     const uint32_t nch = cur & 15u;
     const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
     const ChunkPtr C = (ChunkPtr)__builtin_assume_aligned(M.kd_apx4 + first, 64);
+    // the group's centre (a scalar load beside the chunk loads), the query relative to it, its squared norm
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 cg = ((const __attribute__((address_space(4))) f32x4*)M.kd_actr)[first >> 2];
+    const float X2 = qx - cg.x, Y2 = qy - cg.y, Z2 = qz - cg.z;  // t = fl(q - cg); the slots hold -2 w
+    const float Qg = __builtin_fmaf(X2, X2, __builtin_fmaf(Y2, Y2, Z2 * Z2));
     float gm = __builtin_inff();  // (a NaN never enters: fminf keeps the other operand)
 #define SDFK_APX_SLOT(A, O_)                                                               \
     __builtin_fmaf(X2, __uint_as_float(A[O_]),                                             \
@@ -354,6 +382,7 @@ __device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y
     }
 #undef SDFK_APX_CHUNK
 #undef SDFK_APX_SLOT
+    gm += Qg;  // the estimate of the squared distance itself (+inf stays +inf; inf - inf = NaN never enters below)
     // sorted insert of this group's minimum into B1..B4 (+ the groups of the first three);
     // skipped when no lane's top four change (the insert is then the identity)
     if (DEDUPE && (cur == S.H1 || cur == S.H2 || cur == S.H3)) gm = __builtin_inff();
@@ -375,16 +404,16 @@ __device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y
 // =========================================================================================
 // Approximate first pass (strict mode).  The exact evaluation spends 10 VALU per (query, vertex) on the
 // reference's arithmetic although almost every vertex it meets is NOT the nearest one.
-// Here a slot costs 4: with the vertex's squared norm in the padding word of kd_pts4,
-//     a(v) = fma(-2qx, vx, fma(-2qy, vy, fma(-2qz, vz, |v|^2)))  ~  D(v) - |q|^2
-// orders the vertices of one lane like nanoflann's fp32 distance D(v) up to a known error: with
-// u = 2^-24, S = max|v|^2 + 2 sum_i |q_i| max|v_i| and Q = |q|^2 (fp32 Qf),
-//     |a(v) + Qf - d^2(v)|  <=  u (4 S + 3 Q) =: Ea      (three roundings of partial sums <= S, the
-//                                                        rounding of |v|^2, the error of Qf)
+// Here a slot costs 3 FMA + half a min3: per packet group g with centre cg (k_apx_fill) the slots hold
+// -2 w, |w|^2 for w = fl(v - cg), the lane forms t = fl(q - cg), |t|^2 once per group, and
+//     est(v) = fma(tx, -2wx, fma(ty, -2wy, fma(tz, -2wz, |w|^2))) + |t|^2   ~   D(v)
+// orders the vertices of one lane like nanoflann's fp32 distance D(v) up to the error E(est) derived at
+// apx_err() above: u (16 est + 24 R^2), R the largest group radius — of the size of the distance and of a
+// group, not of the scene (round 2 centred on the mesh: u (5 S + 4 Q) with S, Q the scene's squared size,
+// which ruled the pass out for dense meshes).  With
 //     D(v) = d^2(v) (1 + t), |t| <= 5.01 u               (nanoflann.hpp:432-440, five roundings)
-// so  lower(a) = (a + Qf - Ea)(1 - 8u)  <=  D(v)  <=  (a + Qf + Ea)(1 + 8u) = upper(a)   (constants
-// rounded up; Ea is computed with 5 S + 4 Q).  Per lane the walk keeps the four smallest GROUP
-// minima B1 <= B2 <= B3 <= B4 of a() and the groups of the first three.  Pruning uses upper(B1)*c^2,
+// lower(est) <= D(v) <= upper(est).  Per lane the walk keeps the four smallest GROUP
+// minima B1 <= B2 <= B3 <= B4 of est and the groups of the first three.  Pruning uses upper(B1)*c^2,
 // an upper bound of what the exact walk would use, so every vertex the exact walk needs is met.
 // Afterwards each lane evaluates EXACTLY (reference arithmetic, tie rules of the exact walk) the
 // groups whose minimum could still be the nearest: H1, and Hk while lower(Bk) <= upper(B1).
@@ -394,7 +423,7 @@ __device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y
 // decision logic needs of `s`.  A fourth candidate group defers the query to the strict kernel.
 // =========================================================================================
 
-// The walk itself.  APPROX: SA is updated (thresholds from upper(B1) * c^2 = max(B1 + Qe, 0) * cm),
+// The walk itself.  APPROX: SA is updated (thresholds from upper(B1) * c^2, cm = c^2),
 // else SE (thresholds b * c^2).  Returns true when the wave gave up (work budget, see k_query_heavy).
 // CONT (cooperative kernel, APPROX only): SA holds the state of a walk that passed M.coop_budget in the main
 // kernel; this wave continues it over the L1 nodes j with j % nparts == part (the walk is redone from the
@@ -405,8 +434,8 @@ __device__ __forceinline__ void group_approx(const MeshDev& M, float X2, float Y
 // queries go straight to the heavy list (no walk, no cooperative continuation); when that list is long the host
 // has the strict kernel answer it, each lane walking the tree for itself, instead of the exact scan.
 template <bool APPROX, bool CONT>
-__device__ __forceinline__ uint32_t packet_walk(const MeshDev& M, float qx, float qy, float qz, float ax, float ay,
-                                            float az, float Qe, float cm, ExactState& SE, ApproxState& SA,
+__device__ __forceinline__ uint32_t packet_walk(const MeshDev& M, float qx, float qy, float qz, float cm,
+                                            ExactState& SE, ApproxState& SA,
                                             uint32_t part, uint32_t nparts, uint32_t budget) {
     const uint32_t lane = threadIdx.x & 63u;
     SDFK_COUNT(0, 1);
@@ -425,12 +454,11 @@ __device__ __forceinline__ uint32_t packet_walk(const MeshDev& M, float qx, floa
     // absolute slack of the box tests: 64u x (an upper bound of |c - centre of any box|)
     const float reach = ((fabsf(cx - M.obb_cm[0]) + fabsf(cy - M.obb_cm[1])) + fabsf(cz - M.obb_cm[2])) + (M.obb_rm + rho);
     const float Ew = 3.8146973e-6f * reach;
-    const float X2 = -2.f * ax, Y2 = -2.f * ay, Z2 = -2.f * az;  // (a: the query in the approximate pass's frame)
     const float c2 = M.amb_c2;
     float rr = __builtin_inff();  // per lane: sqrt of the lane's threshold, with the slack of the plane test (inf: prunes nothing)
 #define SDFK_PK_REFRESH()                                                                           \
     {                                                                                               \
-        const float thr_ = APPROX ? fmaxf(SA.B1 + Qe, 0.f) * cm : __uint_as_float(SE.b) * c2;       \
+        const float thr_ = APPROX ? apx_upper(M, SA.B1) * cm : __uint_as_float(SE.b) * c2;          \
         rr = __builtin_fmaf(__builtin_amdgcn_sqrtf(thr_), 1.f + PK_EPS, PK_EPS * rho);              \
     }
     // (the thresholds only move when some lane's minimum did: most groups past the first few change nothing)
@@ -441,7 +469,7 @@ __device__ __forceinline__ uint32_t packet_walk(const MeshDev& M, float qx, floa
         work += (REF) & 15u;                                                              \
         const uint32_t old_ = APPROX ? __float_as_uint(SA.B1) : SE.b;                     \
         if (APPROX)                                                                       \
-            group_approx<CONT>(M, X2, Y2, Z2, (REF), SA);                                 \
+            group_approx<CONT>(M, qx, qy, qz, (REF), SA);                                 \
         else                                                                              \
             group_exact(M, qx, qy, qz, (REF), SE);                                        \
         moved = __ballot(old_ != (APPROX ? __float_as_uint(SA.B1) : SE.b)) != 0ull;       \
@@ -593,11 +621,11 @@ __device__ __forceinline__ uint32_t packet_walk(const MeshDev& M, float qx, floa
 //
 // What a list must hold.  Every wave that uses it evaluates entry 0 (the group G0 nearest to the cube's centre
 // c) first.  After that, lane l (query q = c + e, |e_i| <= h_i, |e| <= rho) has a threshold
-//     thr(q) <= (D_q(v0) [exact walk]  |  a_q(v0) + Qf + Ea <= d^2(q, v0) + 2 Ea [approximate walk]) * (1 + ~1e-5)
+//     thr(q) <= (D_q(v0) [exact walk]  |  upper(est_q(v0)) <= d^2(q, v0) (1 + 50u) + 80u R^2 [approximate walk]) * (1 + ~1e-5)
 // for the vertex v0 of G0 nearest to c, and thresholds only shrink.  With d0 = |c - v0|, g = (c - v0) / d0:
 //     |q - v0| = sqrt(d0^2 + 2 d0 g.e + |e|^2) <= d0 + g.e + rho^2 / (2 d0)          (sqrt(1 + x) <= 1 + x / 2)
 // or, near the surface (d0 <= rho),  |q - v0| <= d0 + rho  with g = 0.  Hence for every query of the cube
-//     rr(q) - g.e  <=  res := (d0 + min-form slack + sqrt(2 Ea_max)) (1 + 2^-15) + 2^-15 reach,
+//     rr(q) - g.e  <=  res := (d0 + min-form slack + 3e-3 R) (1 + 2^-15) + 2^-15 reach,
 // and a group whose box lies in the half space {x : n.(x - c) <= -f0} can be left out when
 //     f0 - sum_i |n_i - g_i| h_i > res      (then f0 + n.e > rr(q) for every q of the cube: the walk's own
 //                                            lane-level test, at thresholds no smaller than the final ones)
@@ -713,16 +741,12 @@ __global__ __launch_bounds__(64) void k_cube_lists(MeshDev M, const uint32_t* __
         const bool trend = d0 > rho;  // far enough for the linear trend to pay
         const float inv = trend ? 1.f / d0 : 0.f;
         gx = wx * inv, gy = wy * inv, gz = wz * inv;
-        // Ea_max: the approximate pass's error bound Ea(q) = u (kS S + kQ Q) over the cube (|q - apx_c|_i <= m_i)
-        const float m0 = fabsf(cx - M.apx_c[0]) + hx, m1 = fabsf(cy - M.apx_c[1]) + hy, m2 = fabsf(cz - M.apx_c[2]) + hz;
-        const float V0 = fmaxf(fabsf(M.bb[0] - M.apx_c[0]), fabsf(M.bb[3] - M.apx_c[0]));
-        const float V1 = fmaxf(fabsf(M.bb[1] - M.apx_c[1]), fabsf(M.bb[4] - M.apx_c[1]));
-        const float V2 = fmaxf(fabsf(M.bb[2] - M.apx_c[2]), fabsf(M.bb[5] - M.apx_c[2]));
-        const float S = M.vmax2 + 2.f * ((m0 * V0 + m1 * V1) + m2 * V2);
-        const float Q = (m0 * m0 + m1 * m1) + m2 * m2;
-        const float Ea = 5.9604645e-8f * (M.apx_kS * S + M.apx_kQ * Q) * 1.01f;
+        // The approximate walk's threshold after G0: (est + E(est)) cm with est <= d^2 + E_d, E_d <= u (14 d^2 + 21 R^2):
+        // at most d^2 (1 + 50 u) + 80 u R^2, i.e. d (1 + 25 u) + sqrt(80 u) R in distance — the relative part is far
+        // inside the (1 + 2^-15) below, sqrt(80 u) R = 2.2e-3 R is added (3e-3 sqrt(apx_e0 / (24 u)) = 3e-3 R).
+        const float slackR = 3e-3f * __builtin_amdgcn_sqrtf(M.apx_e0 * (1.f / (24.f * 5.9604645e-8f)));
         const float slack = trend ? (rho * rho) * (0.5f * inv) : rho;
-        d0 = ((d0 + slack) + __builtin_amdgcn_sqrtf(2.f * Ea) * 1.001f) * (1.f + 3.0517578e-5f) + 3.0517578e-5f * reach;
+        d0 = ((d0 + slack) + slackR) * (1.f + 3.0517578e-5f) + 3.0517578e-5f * reach;
     }
     const float res = d0;  // >= rr(q) - g.e of every query of the cube once G0 is evaluated
     // ---- every group the cube-level test cannot exclude, in tree order (slot 0 is G0's)
@@ -883,24 +907,11 @@ __device__ __forceinline__ void packet_to_heavy(bool valid, int64_t i, int64_t s
     if (valid) heavy_list[base + (uint32_t)__popcll(vm & lt)] = off + (uint32_t)src;
 }
 
-// error model of a() for one lane (see "Approximate first pass"); qc: the query in the centred frame
-__device__ __forceinline__ void approx_model(const MeshDev& M, V3 p, V3& qc, float& Qf, float& Ea) {
-    const float u = 5.9604645e-8f;  // 2^-24
-    const float cx = M.apx_c[0], cy = M.apx_c[1], cz = M.apx_c[2];
-    qc = {p.x - cx, p.y - cy, p.z - cz};
-    // >= |v'_i| of every stored vertex: fl(lo - c) and fl(hi - c) bracket fl(v - c) (rounding is monotone)
-    const float Vx = fmaxf(fabsf(M.bb[0] - cx), fabsf(M.bb[3] - cx)), Vy = fmaxf(fabsf(M.bb[1] - cy), fabsf(M.bb[4] - cy)),
-                Vz = fmaxf(fabsf(M.bb[2] - cz), fabsf(M.bb[5] - cz));
-    const float S = M.vmax2 + 2.f * ((fabsf(qc.x) * Vx + fabsf(qc.y) * Vy) + fabsf(qc.z) * Vz);
-    Qf = (qc.x * qc.x + qc.y * qc.y) + qc.z * qc.z;
-    Ea = u * (M.apx_kS * S + M.apx_kQ * Qf);
-}
-
 // What follows the walk, per lane: the exact second phase (APPROX), the decision whether the walk's answer
 // is nanoflann's, and the result (nearest vertex / incident-face distances / sign).
 template <int KIND, bool ROBUST, bool APPROX>
 __device__ __forceinline__ void packet_finish(const MeshDev& M, V3 p, bool valid, int64_t i, int64_t src, float sign,
-                                              PacketBest pb, const ApproxState& A, float Qf, float Ea, int trunc_aabb,
+                                              PacketBest pb, const ApproxState& A, int trunc_aabb,
                                               void* __restrict__ out, unsigned long long* __restrict__ amb_mask,
                                               uint32_t* __restrict__ amb_cnt, uint32_t off,
                                               uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_cnt) {
@@ -913,16 +924,15 @@ __device__ __forceinline__ void packet_finish(const MeshDev& M, V3 p, bool valid
     bool amb = false;
     if (APPROX) {
         // second phase: the groups whose minimum could be the nearest vertex, exactly
-        const float u = 5.9604645e-8f;
-        const float k1p = 1.f + 8.f * u, k1m = 1.f - 8.f * u;
-        const float x1 = A.B1 + (Qf + Ea);
-        const float U = fmaxf(fmaxf(x1 * k1p, x1), 0.f);  // >= D of B1's vertex >= the exact minimum
-        const float y2 = (A.B2 + Qf) - Ea, y3 = (A.B3 + Qf) - Ea, y4 = (A.B4 + Qf) - Ea;
-        const float L2 = fminf(y2 * k1m, y2), L3 = fminf(y3 * k1m, y3), L4 = fminf(y4 * k1m, y4);  // <= D outside
+        const float U = apx_upper(M, A.B1);  // >= D of B1's vertex >= the exact minimum
+        const float L2 = apx_lower(M, A.B2), L3 = apx_lower(M, A.B3), L4 = apx_lower(M, A.B4);  // <= D outside
         // (Widening these tests to the window of the near-tie test below, so that a group's lower bound never
         // stands in for `s` there, was measured: near-tie lanes 2.28 -> 2.18 per wave, step 22.4 -> 23.0 ms.  The
         // near ties are real: far-field squared distances of neighbouring vertices differ by ~1e-5 relative.)
         const bool n2 = !(L2 > U), n3 = n2 && !(L3 > U), n4 = n3 && !(L4 > U);
+#ifdef SDFK_STATS
+        if (valid && n4) atomicAdd(&g_pk_stats[7], 1ull);  // (APPROX: a fourth candidate group)
+#endif
         uint32_t b = 0x7F7FFFFFu, s2 = 0x7F7FFFFFu, hp = H_NONE;
         if (A.H1 != H_NONE && !n4) {
             exact_group<false>(M, p.x, p.y, p.z, A.H1, b, s2, hp);
@@ -994,7 +1004,7 @@ __device__ __forceinline__ void packet_finish(const MeshDev& M, V3 p, bool valid
 #define SDFK_COOP_WAVES 8
 #endif
 constexpr int COOP_WAVES = SDFK_COOP_WAVES;
-constexpr uint32_t COOP_CAP = 16384;  // packets one launch can hand over (28 MiB of lists)
+constexpr uint32_t COOP_CAP = 32768;  // packets one launch can hand over (56 MiB of lists); the packets beyond go to the exact scan
 struct CoopDesc {
     uint32_t* list;   // [COOP_CAP] packet (wave) index within the launch
     uint32_t* state;  // [COOP_CAP][7][64]: B1..B4 (float bits), H1..H3
@@ -1032,15 +1042,11 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
     ExactState SE = {0x7F7FFFFFu, 0x7F7FFFFFu, H_NONE, 0xFFFFFFFFu};  // FLT_MAX bits (KNNResultSet::init)
     const float INF = __builtin_inff();
     ApproxState A = {INF, INF, INF, INF, H_NONE, H_NONE, H_NONE};
-    float Qf = 0.f, Ea = 0.f;
     uint32_t wr;
     if (APPROX) {
-        V3 qc;
-        approx_model(M, p, qc, Qf, Ea);
-        wr = packet_walk<true, false>(M, p.x, p.y, p.z, qc.x, qc.y, qc.z, Qf + Ea,
-                                      (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A, 0u, 1u, M.heavy_budget);
+        wr = packet_walk<true, false>(M, p.x, p.y, p.z, M.amb_c2, SE, A, 0u, 1u, M.heavy_budget);
     } else {
-        wr = packet_walk<false, false>(M, p.x, p.y, p.z, p.x, p.y, p.z, 0.f, 1.f, SE, A, 0u, 1u, M.heavy_budget);
+        wr = packet_walk<false, false>(M, p.x, p.y, p.z, 1.f, SE, A, 0u, 1u, M.heavy_budget);
         if (SE.b == SE.tieb) SE.s2 = SE.b;  // a settled exact tie is a tie
         pb.b = __uint_as_float(SE.b), pb.s = __uint_as_float(SE.s2), pb.h = SE.h;
     }
@@ -1070,7 +1076,7 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
         }
         return;
     }
-    packet_finish<KIND, ROBUST, APPROX>(M, p, valid, i, src, sign, pb, A, Qf, Ea, trunc_aabb, out, amb_mask, amb_cnt, off,
+    packet_finish<KIND, ROBUST, APPROX>(M, p, valid, i, src, sign, pb, A, trunc_aabb, out, amb_mask, amb_cnt, off,
                                         heavy_list, heavy_cnt);
 }
 
@@ -1111,11 +1117,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) SDFK_PK_SGPR void k_query_packet_c
         ApproxState A = {__uint_as_float(st[0]),   __uint_as_float(st[64]), __uint_as_float(st[128]),
                          __uint_as_float(st[192]), st[256],                 st[320],
                          st[384]};
-        float Qf, Ea;
-        V3 qc;
-        approx_model(M, p, qc, Qf, Ea);
-        const bool over = packet_walk<true, true>(M, p.x, p.y, p.z, qc.x, qc.y, qc.z, Qf + Ea,
-                                                  (1.f + 8.f * 5.9604645e-8f) * M.amb_c2, SE, A,
+        const bool over = packet_walk<true, true>(M, p.x, p.y, p.z, M.amb_c2, SE, A,
                                                   wave, (uint32_t)COOP_WAVES, max(M.coop_budget, M.heavy_budget / 4u)) != 0u;
         if (lane == 0) s_over[wave] = over ? 1u : 0u;
         if (wave != 0) {
@@ -1155,7 +1157,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) SDFK_PK_SGPR void k_query_packet_c
                 if (ROBUST && KIND != Q_NN) sign = raycast_packet(M, p, valid);
                 PacketBest pb;
                 pb.bailed = false;
-                packet_finish<KIND, ROBUST, true>(M, p, valid, i, src, sign, pb, A, Qf, Ea, trunc_aabb, out, amb_mask,
+                packet_finish<KIND, ROBUST, true>(M, p, valid, i, src, sign, pb, A, trunc_aabb, out, amb_mask,
                                                   amb_cnt, off, heavy_list, heavy_cnt);
             }
         }

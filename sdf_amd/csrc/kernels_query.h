@@ -41,10 +41,11 @@ struct MeshDev {
     uint32_t heavy_budget;  // packet pass: a wave that has evaluated more chunks than this gives up
     uint32_t coop_budget;   // ... and hands its packet to the cooperative kernel past this many (approximate walk)
     float amb_c, amb_c2;
-    float vmax2;  // max |v - apx_c|^2 over the vertices, rounded up (approximate first pass)
-    float apx_c[3];          // centre the approximate pass works around (fp32 centre of the mesh AABB, or 0)
-    float apx_kS, apx_kQ;    // its error model: Ea = u (kS S + kQ Q); (5, 4) without centring, (7, 6) with
-    const float4* kd_apx4;   // per tree position: fl(v - apx_c), |fl(v - apx_c)|^2 (+inf for sentinels)
+    // approximate first pass, group-centred (k_apx_fill): per tree position -2 fl(v - cg), |fl(v - cg)|^2 (+inf for
+    // sentinels); per 4 positions the centre cg of the group they belong to; the error model E(est) = apx_k1 est + apx_e0
+    const float4* kd_apx4;
+    const float4* kd_actr;
+    float apx_k1, apx_e0;
     // adjacency + face geometry
     const uint32_t* adj_off;
     const int32_t* adj_faces;

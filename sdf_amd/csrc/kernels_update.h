@@ -102,17 +102,53 @@ __global__ void k_leaf_boxes(const float4* __restrict__ pn, uint32_t nnodes, uin
     }
 }
 
-__global__ void k_apx_fill(const float4* __restrict__ pts4, uint32_t n, float cx, float cy, float cz,
-                           float4* __restrict__ apx4) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 P = pts4[i];
-    if (!(P.w < __builtin_inff())) {  // sentinel slot (or a non-finite vertex: its a() must never be a minimum)
-        apx4[i] = make_float4(0.f, 0.f, 0.f, __builtin_inff());
+// The approximate pass's copy of the vertices, centred per packet group (round 3): group g with centre cg (its
+// box centre; any fp32 point near the group will do) stores per slot  w2 = -2 fl(v - cg)  and  W = |fl(v - cg)|^2
+// (rounded once from double; +inf for sentinel slots and non-finite vertices: their estimate is never a minimum),
+// and cg itself at actr[first position / 4].  A lane then estimates d^2(q, v) as
+//     fma(t.x, w2.x, fma(t.y, w2.y, fma(t.z, w2.z, W))) + |t|^2,   t = fl(q - cg),
+// whose products are of the size of the group (|w| <= R ~ 0.03), not of the scene: the error is
+// u (14 d^2 + 21 R^2) instead of u (5 S + 4 Q) with S, Q of the order of the scene's squared size (kernels_packet.h).
+// One thread per group; the thread after the last group fills the tail pad.  rmax2_bits[0]: max W over the real
+// slots, [1]: set when a finite vertex could not be stored.
+__global__ void k_apx_fill(const uint32_t* __restrict__ grefs, uint32_t ngroups, const float4* __restrict__ gobb_aos,
+                           const float4* __restrict__ pts4, const int32_t* __restrict__ vind, uint32_t npos,
+                           uint32_t nalloc, float4* __restrict__ apx4,
+                           float4* __restrict__ actr, uint32_t* __restrict__ rmax2_bits) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const float inf = __builtin_inff();
+    if (g == ngroups) {
+        for (uint32_t k = npos; k < nalloc; ++k) apx4[k] = make_float4(0.f, 0.f, 0.f, inf);
+        for (uint32_t k = npos >> 2; k < (nalloc + 3u) >> 2; ++k) actr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
-    const float x = P.x - cx, y = P.y - cy, z = P.z - cz;
-    apx4[i] = make_float4(x, y, z, (float)(((double)x * x + (double)y * y) + (double)z * z));
+    if (g > ngroups) return;
+    const uint32_t ref = grefs[g];
+    const uint32_t first = ((ref & sdfk::KD_REF_MASK) >> 4) << 2, n4 = 4u * (ref & 15u);
+    const float4 A = gobb_aos[4u * (size_t)g];
+    const bool okc = fabsf(A.x) <= FLT_MAX && fabsf(A.y) <= FLT_MAX && fabsf(A.z) <= FLT_MAX;
+    const float cx = okc ? A.x : 0.f, cy = okc ? A.y : 0.f, cz = okc ? A.z : 0.f;
+    float rmax2 = 0.f;
+    uint32_t wild = 0u;
+    for (uint32_t k = first; k < first + n4; ++k) {
+        const float4 P = pts4[k];
+        const float x = P.x - cx, y = P.y - cy, z = P.z - cz;
+        const float W = (float)(((double)x * x + (double)y * y) + (double)z * z);
+        if (vind[k] < 0 || !(W <= FLT_MAX)) {  // sentinel slot, or a vertex no finite arithmetic covers
+            apx4[k] = make_float4(0.f, 0.f, 0.f, inf);
+            // A vertex with finite coordinates whose distance from its group's centre overflows (a group ~1e19 wide)
+            // would be invisible to the pass although some query may have it nearest: the host turns the pass off
+            // for such a mesh (rmax2_bits[1] != 0).  Non-finite vertices are never nearest to anything.
+            const bool real = vind[k] >= 0 && fabsf(P.x) <= FLT_MAX && fabsf(P.y) <= FLT_MAX && fabsf(P.z) <= FLT_MAX;
+            if (real) wild = 1u;
+        } else {
+            apx4[k] = make_float4(-2.f * x, -2.f * y, -2.f * z, W);
+            rmax2 = fmaxf(rmax2, W);
+        }
+    }
+    for (uint32_t k = first >> 2; k < (first + n4) >> 2; ++k) actr[k] = make_float4(cx, cy, cz, 0.f);
+    atomicMax(rmax2_bits, __float_as_uint(rmax2));  // (non-negative floats order like their bits)
+    if (wild) atomicOr(rmax2_bits + 1, 1u);
 }
 
 __global__ void k_face_precompute(const float* __restrict__ verts, const uint32_t* __restrict__ faces,

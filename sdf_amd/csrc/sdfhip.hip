@@ -187,7 +187,12 @@ struct sdfhip_ctx {
     int32_t* d_kd_vind = nullptr;
     size_t kd_nodes_cap = 0, kd_pos_cap = 0;
     float4* d_kd_pts4 = nullptr;
-    float4* d_kd_apx4 = nullptr;  // the approximate pass's centred copy (k_apx_fill)
+    float4* d_kd_apx4 = nullptr;  // the approximate pass's group-centred copy (k_apx_fill) ...
+    float4* d_kd_actr = nullptr;  // ... the groups' centres, one per 4 positions ...
+    uint32_t* d_apx_r2 = nullptr; // ... and [0] the largest squared group radius (bits of a float), [1] != 0: unusable
+    uint32_t apx_r2_bits[2] = {0, 0};
+    bool apx_usable = false;      // false: a vertex the pass cannot represent (k_apx_fill); the exact walk is taken
+    float apx_k1 = 0.f, apx_e0 = 0.f;  // error model of the pass: E(est) = apx_k1 est + apx_e0 (fill_apx)
     float4* d_kd_lbox = nullptr;  // per position: its leaf's tight box (k_leaf_boxes, kd_path_clear)
     size_t kd_lbox_cap = 0, kd_apx_cap = 0;  // (capacities of their own: the GPU-built tree of fast_nn has neither array)
     // the strict tree the device arrays currently hold — built by this handle's own update, or by the leader of
@@ -195,8 +200,6 @@ struct sdfhip_ctx {
     int32_t kd_depth = 0;
     uint32_t kd_root = 0, kd_npos = 0, kd_nnodes = 0;
     int64_t kd_builds = 0;  // host kd-tree builds this handle has run (sdfhip_stats_t::kd_builds)
-    float apx_c[3] = {0.f, 0.f, 0.f};
-    bool apx_centred = false;
     float amb_c = 1.f, amb_c2 = 1.f;
     QueryWs ws;            // this handle's own query workspace, grown on demand
     QueryWs* W = &ws;      // the workspace of the running call (the static scratch in the no-alloc entry)
@@ -213,8 +216,8 @@ struct sdfhip_ctx {
     int64_t opt_cube_level = 0;    // cubes per axis = 2^level; 0 automatic (~4096 queries per cube)
     int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
     bool approx_ok = false;   // decided by every update(): see approx_pays()
+    bool approx_pre = false;  // ... its value when the tree was uploaded (fill_apx may still turn it off; read by followers)
     int64_t opt_packet_group = 0;  // vertices per packet group: 0 automatic (40 with the approximate pass, else 24)
-    float vmax2 = 0.f;        // max |v|^2 over the vertices, rounded up (strict mode)
     int64_t opt_build_threads = 1;
     uint32_t* d_adj_off = nullptr;
     int32_t* d_adj_faces = nullptr;
@@ -680,25 +683,21 @@ int build_fast_tree(sdfhip_ctx* h) {
     return build_obbs(h, ngroups);
 }
 
-// The approximate first pass of the packet kernel orders vertices by a() = |v|^2 - 2 q.v, whose
-// absolute error ~ 5u S (S = max|v|^2 + 2 sum |q_i| max|v_i|, u = 2^-24) does not shrink with the
-// distance between neighbouring vertices.  Every group whose minimum lies within 2E of the best
-// is re-evaluated exactly, a fourth one sends the query to the exact scan — results never depend
-// on it, the time does.  Expected number of vertices in that window for a query near a surface of
-// vertex density rho: lambda = rho * pi * 2E.  It pays while lambda is small: not for meshes far
-// from the origin against their size (S large), nor for very dense ones.  rho is taken from the
-// surface of the AABB, |q_i| ~ max|v_i|; both crude, the threshold is generous.
-// E: the absolute window of the approximate pass (Ea for a query at the mesh), lambda: vertices per window
+// The approximate first pass of the packet kernel orders the vertices of a lane by an estimate of the squared
+// distance whose error E = u (16 d^2 + 24 R^2) (u = 2^-24, d the distance, R the radius of a packet group:
+// kernels_packet.h, apx_err) is of the size of the distance, not of the scene.  Every group whose minimum lies
+// within 2E of the best is re-evaluated exactly, a fourth one sends the query to the exact scan — results never
+// depend on it, the time does.  Expected number of vertices in that window for a query at distance d from a
+// surface of vertex density rho: lambda = rho * pi * 2E.  rho is taken from the surface of the AABB, d as a
+// quarter of its diagonal (queries spread over the mesh's own box); both crude, the threshold is generous.
+// E: the absolute window of the approximate pass, lambda: vertices per window
 bool approx_window(const sdfhip_ctx* h, double& E, double& lambda) {
-    double V[3], e[3];
-    for (int d = 0; d < 3; ++d) {  // (the pass works in a frame centred on the mesh: V = half extents)
-        V[d] = std::fmax(std::fabs((double)h->aabb[d] - h->apx_c[d]), std::fabs((double)h->aabb[d + 3] - h->apx_c[d]));
-        e[d] = (double)h->aabb[d + 3] - (double)h->aabb[d];
-    }
-    const double S = 3.0 * (V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
-    E = 5.9604644775390625e-8 * (h->apx_centred ? 7.0 : 5.0) * S;
+    double e[3];
+    for (int d = 0; d < 3; ++d) e[d] = (double)h->aabb[d + 3] - (double)h->aabb[d];
+    const double diag2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    E = 5.9604644775390625e-8 * 16.0 * diag2 / 16.0;
     const double area = 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
-    if (!(area > 0.0) || !std::isfinite(area) || !std::isfinite(S)) return false;
+    if (!(area > 0.0) || !std::isfinite(area) || !std::isfinite(diag2)) return false;
     lambda = (double)h->nv / area * 3.141592653589793 * 2.0 * E;
     return true;
 }
@@ -707,17 +706,14 @@ bool approx_pays(const sdfhip_ctx* h) {
     if (h->nv < 64) return false;
     double E, lambda;
     if (!approx_window(h, E, lambda)) return false;
-    // (tori of 360k / 490k / 640k / 1M vertices, lambda = 0.34 / 0.47 / 0.61 / 0.95, 32M random points: nn 10.5 / 14.7 /
-    // 22.1 / 231 ms with the pass, 12.8 / 17.2 / 22.8 / 32.8 ms without: tools/scale_probe.py <res> approx=<0|1>)
     return lambda <= APPROX_LAMBDA_MAX;
 }
 // The same question per packet group, once the groups exist: a mesh whose vertices crowd in one place (a fine
 // part in a coarse scene) passes the average test while every query that has the fine part nearest meets four
-// candidate groups and goes to the exact scan — a pass over all vertices each (424^2 torus + a copy shrunk to 1 %
-// beside it, 32M random points: nn 195 ms with the pass, 39 ms without).  Density of a group: its vertices over the
-// disc of its box's half diagonal.  Every fourth group is looked at; more than 2 % of the vertices seen in groups
-// denser than four times the limit on the average turn the pass off (a torus is twice as dense inside as outside,
-// and the limit on the average was tuned on tori).
+// candidate groups and goes to the exact scan — a pass over all vertices each.  Density of a group: its vertices
+// over the disc of its box's half diagonal.  Every fourth group is looked at; more than 2 % of the vertices seen
+// in groups denser than four times the limit on the average turn the pass off (a torus is twice as dense inside
+// as outside, and the limit on the average was tuned on tori).
 bool approx_pays_locally(const sdfhip_ctx* h) {
     double E, lambda;
     if (!approx_window(h, E, lambda)) return false;
@@ -759,6 +755,9 @@ int reserve_strict_tree(sdfhip_ctx* h, size_t nnodes, size_t nalloc) {
     }
     if (nalloc > h->kd_apx_cap) {
         if (int rc = dalloc(&h->d_kd_apx4, nalloc)) return rc;
+        if (int rc = dalloc(&h->d_kd_actr, nalloc / 4 + 4)) return rc;
+        if (!h->d_apx_r2)
+            if (int rc = dalloc(&h->d_apx_r2, 2)) return rc;
         h->kd_apx_cap = nalloc;
     }
     if (nalloc > h->kd_lbox_cap) {
@@ -768,11 +767,43 @@ int reserve_strict_tree(sdfhip_ctx* h, size_t nnodes, size_t nalloc) {
     return 0;
 }
 
+// The approximate pass's copy of the tree positions (k_apx_fill; needs the groups' boxes: after build_obbs) and the
+// error model that goes with it, E(est) = apx_k1 est + apx_e0 = u (16 est + 24 R^2), rounded up; R^2 = the largest
+// |fl(v - cg)|^2 the kernel met.  Synchronizes the stream.
+int fill_apx(sdfhip_ctx* h, uint32_t ngroups, size_t nalloc) {
+    hipStream_t s = h->stream;
+    HIPC(hipMemsetAsync(h->d_apx_r2, 0, 2 * sizeof(uint32_t), s));
+    k_apx_fill<<<(ngroups + 1u + 255u) / 256u, 256, 0, s>>>(h->d_kd_gref, ngroups, h->d_kd_gobb_aos, h->d_kd_pts4, h->d_kd_vind,
+                                                          h->kd_npos, (uint32_t)nalloc, h->d_kd_apx4, h->d_kd_actr, h->d_apx_r2);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(h->apx_r2_bits, h->d_apx_r2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    float r2;
+    std::memcpy(&r2, &h->apx_r2_bits[0], sizeof r2);
+    const double u = 5.9604644775390625e-8;
+    auto up = [](double x) {
+        float f = (float)x;
+        return (double)f < x ? std::nextafter(f, FLT_MAX) : f;
+    };
+    h->apx_k1 = up(16.0 * u * 1.001);
+    h->apx_e0 = up(24.0 * u * (double)r2 * 1.001);
+    h->apx_usable = h->apx_r2_bits[1] == 0u && std::isfinite(h->apx_e0);
+    // The absolute term alone as a window (approx_window): one stray group as wide as the scene makes every query
+    // ambiguous.  (Followers of a group take the same decision from the same data.)
+    double E, lambda;
+    if (h->approx_ok && approx_window(h, E, lambda)) {
+        lambda *= (double)h->apx_e0 / E;
+        if (!(lambda <= APPROX_LAMBDA_MAX)) h->approx_ok = false;
+    }
+    if (!h->apx_usable) h->approx_ok = false;
+    return 0;
+}
+
 // A group update (group.h): the leader builds the tree once and tells the other members how far it is.
 //   stage 1: the new vertices are enqueued on the leader's stream (ev_verts recorded behind them); the mesh
 //            AABB, the rotation and the centre of the approximate pass are final
 //   stage 2: every upload of the strict tree is enqueued (ev_tree recorded behind them); the scalars that
-//            describe the tree (kd_depth .. vmax2, approx_ok) are final
+//            describe the tree (kd_depth .. kd_nnodes, approx_ok) are final
 // fail(): the leader's update ended with an error; waiting members give up with it.
 struct UpdateSync {
     std::mutex mu;
@@ -816,21 +847,6 @@ int do_update(sdfhip_ctx* h, bool draw_R, UpdateSync* sync = nullptr) {
     if (int rc = wait_for_queries(h, s)) return rc;  // queries still in flight read what update rewrites
     // mesh AABB (sdf.cpp:36-37; == the kd root box): needed by the device side before the tree
     h->kd.bounds(h->h_verts, h->nv, (int)h->opt_build_threads, h->aabb);
-    {   // Centre of the approximate pass: the fp32 centre of the AABB when the mesh lies off the origin against its
-        // size (then a() is evaluated on fl(v - c), fl(q - c): two more roundings in the error model, constants
-        // (7, 6), but S and Q shrink to the mesh's own scale); the origin otherwise (exact inputs, constants (5, 4)).
-        float c[3], half = 0.f, dist = 0.f;
-        bool finite = true;
-        for (int d = 0; d < 3; ++d) {
-            c[d] = 0.5f * h->aabb[d] + 0.5f * h->aabb[d + 3];
-            finite = finite && std::isfinite(c[d]) && std::isfinite(h->aabb[d + 3] - h->aabb[d]);
-            half = std::fmax(half, 0.5f * (h->aabb[d + 3] - h->aabb[d]));
-            dist = std::fmax(dist, std::fabs(c[d]));
-        }
-        const bool centre = finite && dist > 0.5f * half;
-        for (int d = 0; d < 3; ++d) h->apx_c[d] = centre ? c[d] : 0.f;
-        h->apx_centred = centre;
-    }
     h->approx_ok = approx_pays(h);
     // Packet groups: a slot of the approximate pass costs 3.5 VALU against 10 of the exact walk, so
     // larger groups (fewer box tests and sorted inserts per wave) pay there.  Measured on
@@ -881,31 +897,25 @@ int do_update(sdfhip_ctx* h, bool draw_R, UpdateSync* sync = nullptr) {
     // vertices in (padded) tree order; sentinel slots are far away: their distance is +inf
     const size_t npos = h->kd.pos_vert.size();
     const size_t nalloc = npos + 16;
-    auto fill = std::async(std::launch::async, [h, npos, nalloc]() -> float {
-        float vmax2 = 0.f;  // max |v|^2 (rounded up below): the error model of the approximate pass
+    auto fill = std::async(std::launch::async, [h, npos, nalloc]() {
         h->perm_pts4.resize(4 * nalloc);
         float* dst = h->perm_pts4.data();
         for (size_t i = 0; i < nalloc; ++i) {
             const int32_t vi = i < npos ? h->kd.pos_vert[i] : -1;
             if (vi < 0) {
                 dst[4 * i] = dst[4 * i + 1] = dst[4 * i + 2] = 3.0e38f;
-                dst[4 * i + 3] = __builtin_inff();  // a() of a sentinel is +inf or NaN, never a minimum
+                dst[4 * i + 3] = __builtin_inff();
             } else {
                 const float* src = h->h_verts + 3 * (size_t)vi;
                 dst[4 * i] = src[0], dst[4 * i + 1] = src[1], dst[4 * i + 2] = src[2];
                 // (w: finite for a vertex, +inf for a sentinel; k_apx_fill tells them apart by it)
                 dst[4 * i + 3] = (float)(((double)src[0] * src[0] + (double)src[1] * src[1]) + (double)src[2] * src[2]);
-                // max |v'|^2 of the approximate pass's centred copy, with k_apx_fill's own arithmetic
-                const float x = src[0] - h->apx_c[0], y = src[1] - h->apx_c[1], z = src[2] - h->apx_c[2];
-                const float w = (float)(((double)x * x + (double)y * y) + (double)z * z);
-                if (w > vmax2) vmax2 = w;
             }
         }
-        return vmax2;
     });
     auto tq0 = std::chrono::steady_clock::now();
     h->kd.build_groups();
-    h->vmax2 = std::nextafter(fill.get(), FLT_MAX);
+    fill.get();
     if (h->approx_ok) h->approx_ok = approx_pays_locally(h);
     auto tq1 = std::chrono::steady_clock::now();
     const int rc_dev = dev_side.get();
@@ -929,8 +939,6 @@ int do_update(sdfhip_ctx* h, bool draw_R, UpdateSync* sync = nullptr) {
                             hipMemcpyHostToDevice, s));
     HIPC(hipMemcpyAsync(h->d_kd_pts4, h->perm_pts4.data(), sizeof(float) * 4 * nalloc,
                         hipMemcpyHostToDevice, s));
-    k_apx_fill<<<(uint32_t)((nalloc + 255) / 256), 256, 0, s>>>(h->d_kd_pts4, (uint32_t)nalloc, h->apx_c[0], h->apx_c[1],
-                                                               h->apx_c[2], h->d_kd_apx4);
     if (!h->kd.nodes.empty()) {
         HIPC(hipMemcpyAsync(h->d_kd_pn, h->kd.nodes.data(), sizeof(sdfk::KdNodeH) * h->kd.nodes.size(),
                             hipMemcpyHostToDevice, s));
@@ -947,12 +955,14 @@ int do_update(sdfhip_ctx* h, bool draw_R, UpdateSync* sync = nullptr) {
                             hipMemcpyHostToDevice, s));
     h->kd_depth = h->kd.depth, h->kd_root = h->kd.root_ref;
     h->kd_npos = (uint32_t)npos, h->kd_nnodes = (uint32_t)h->kd.nodes.size();
+    h->approx_pre = h->approx_ok;
     if (sync) {  // (before the boxes: the other members build their own from the copied tree)
         HIPC(hipEventRecord(sync->ev_tree, s));
         sync->post(2);
     }
     if (int rc = build_obbs(h, (uint32_t)h->kd.groups.size())) return rc;
-    HIPC(hipStreamSynchronize(s));  // host arrays are pageable and rebuilt by the next update
+    if (int rc = fill_apx(h, (uint32_t)h->kd.groups.size(), nalloc)) return rc;  // (ends with a stream synchronize:
+                                                                                 // host arrays are pageable and rebuilt by the next update)
     h->last_update_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("SDFHIP_DEBUG")) {
@@ -986,16 +996,20 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.kd_pts4 = h->d_kd_pts4;
     M.kd_apx4 = h->d_kd_apx4;
     M.kd_lbox = h->d_kd_lbox;
-    for (int d = 0; d < 3; ++d) M.apx_c[d] = h->apx_c[d];
-    M.apx_kS = h->apx_centred ? 7.f : 5.f, M.apx_kQ = h->apx_centred ? 6.f : 4.f;
+    M.kd_actr = h->d_kd_actr;
+    M.apx_k1 = h->apx_k1, M.apx_e0 = h->apx_e0;
     M.kd_npos = h->fast_active ? (uint32_t)(FAST_GROUP * ((h->nv + FAST_GROUP - 1) / FAST_GROUP))
                                : h->kd_npos;
     // a wave may walk 1/8 of the tree (4 positions per chunk) before it hands its queries over
     M.heavy_budget = h->opt_heavy_budget > 0 ? (uint32_t)h->opt_heavy_budget
                                              : (M.kd_npos / 32u > 4096u ? M.kd_npos / 32u : 4096u);
-    M.coop_budget = (uint32_t)std::min<int64_t>(h->opt_coop_budget < 0 ? 1500 : h->opt_coop_budget, M.heavy_budget);
+    // hand-over budget of the cooperative continuation: 1500 work units on the bench mesh (230k positions); a wave's
+    // ordinary walk grows with the tree (groups of 60 from 600k vertices on), and every packet beyond COOP_CAP goes
+    // to the exact scan: 1M-vertex torus, 32M points, budget 1500 / 3000 / 4500 / 6000 / 10000 / 20000:
+    // nn 63.2 (164k queries in the scan) / 22.0 / 21.5 / 21.8 / 22.1 / 25.3 ms
+    const int64_t coop_auto = std::min<int64_t>(std::max<int64_t>(1500, (int64_t)M.kd_npos / 280), 6000);
+    M.coop_budget = (uint32_t)std::min<int64_t>(h->opt_coop_budget < 0 ? coop_auto : h->opt_coop_budget, M.heavy_budget);
     M.amb_c = h->amb_c;
-    M.vmax2 = h->vmax2;
     M.amb_c2 = h->amb_c2;
     M.adj_off = h->d_adj_off;
     M.adj_faces = h->d_adj_faces;
@@ -1299,7 +1313,7 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             if (int rc = prof.begin()) return rc;
             // strict mode: approximate first pass + exact second phase (kernels_packet.h); the GPU-built
             // tree of fast_nn has no strict kernel behind it and keeps the exact walk
-            const bool approx = !fast && (h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0);
+            const bool approx = !fast && h->apx_usable && (h->opt_approx < 0 ? h->approx_ok : h->opt_approx != 0);
             h->last_kernel = approx ? SDFHIP_KERNEL_PACKET_APPROX : SDFHIP_KERNEL_PACKET_EXACT;
             // Long walks go on in the cooperative kernel (8 waves per packet); not for ray-only contains().
             // It is one more serial phase (~0.3 ms): it pays most while the launch is short enough for its few
@@ -1890,7 +1904,7 @@ void sdfhip_destroy(sdfhip_t* h) {
                     h->d_adj_faces, h->d_geo, h->d_geo_adj, h->d_rface, h->d_area_cum, h->d_fbox, h->d_normals, h->d_areas,
                     h->d_rnodes, h->d_sorted_face, h->d_codes, h->d_maxdepth, h->topo.lo, h->topo.hi,
                     h->topo.split, h->topo.parentI, h->topo.parentL, h->topo.posI, h->topo.posL,
-                    h->topo.depthI, h->ws.qkeys, h->ws.qperm, h->ws.qbounds, h->d_gstack, h->d_kd_pts4, h->d_kd_apx4, h->d_kd_lbox,
+                    h->topo.depthI, h->ws.qkeys, h->ws.qperm, h->ws.qbounds, h->d_gstack, h->d_kd_pts4, h->d_kd_apx4, h->d_kd_actr, h->d_apx_r2, h->d_kd_lbox,
                     h->ws.fb_list, h->ws.fb_count, h->ws.heavy_pos, h->ws.coop_list, h->ws.coop_state, h->ws.amb_mask, h->ws.amb_cnt, h->ws.amb_s1, h->ws.amb_s2,
                     h->d_vkeys, h->d_vidx};
     for (void* p : ptrs)

@@ -11,13 +11,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--mesh", default="torus"); ap.add_argument("--noise", type=float, default=0.0)
 ap.add_argument("--n", type=int, default=16_000_000); ap.add_argument("--grid", type=int, default=0)
 ap.add_argument("--fast-nn", type=int, default=0); ap.add_argument("--group", type=int, default=0)
+ap.add_argument("--res", type=int, default=424); ap.add_argument("--approx", type=int, default=-1)
 ap.add_argument("--repeat", type=int, default=1, help="every point R times in a row: a wave then holds 64/R distinct queries")
 a = ap.parse_args()
-v, f = meshes.torus(424, 424) if a.mesh == "torus" else meshes.icosphere(int(a.mesh[3:]), radius=0.8, noise=a.noise, seed=3)
+v, f = meshes.torus(a.res, a.res) if a.mesh == "torus" else meshes.icosphere(int(a.mesh[3:]), radius=0.8, noise=a.noise, seed=3)
 s = sdf_amd.SDF(v, f, robust=False)
 if a.fast_nn: s.set_option("fast_nn", 1)
 if a.group: s.set_option("packet_group", a.group)
-if a.fast_nn or a.group: s.update()
+if a.approx >= 0: s.set_option('approx', a.approx)
+if a.fast_nn or a.group or a.approx >= 0: s.update()
 dev = torch.device("cuda", 0)
 if a.grid:
     t = torch.linspace(-1, 1, a.grid, device=dev)

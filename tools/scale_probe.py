@@ -18,7 +18,8 @@ dev = torch.device("cuda", 0)
 pts = torch.rand((32_000_000, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(7)).mul_(2).sub_(1)
 for name, fn in (("nn", s.nn), ("contains", s.contains), ("sdf", s.__call__)):
     fn(pts); torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(pts); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"{name:9s} 32M points {dt*1e3:8.2f} ms  {32e6/dt/1e6:8.1f} Mevals/s")
+    st = s.stats
+    print(f"{name:9s} 32M points {dt*1e3:8.2f} ms  {32e6/dt/1e6:8.1f} Mevals/s  fallback {st['last_fallback_points']} heavy {st['last_heavy_points']}")
 hp = pts[:60000].cpu().numpy()
 o = po.OracleSDF(v, f, True, R)
 assert (s.nn(hp) == o.nn(hp)).all() and (s.contains(hp) == o.contains(hp)).all()
