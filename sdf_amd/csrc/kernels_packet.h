@@ -1278,46 +1278,65 @@ __global__ __launch_bounds__(64 * WAVES) void k_query_heavy(MeshDev M, const flo
         // Exact tie (block-uniform): h is the lowest tied position, which is the fast_nn rule;
         // nanoflann's rule wants the tied vertex its DFS meets first: second scan over the
         // vertices at distance exactly b, folded with kd_dfs_first (a total order for a fixed
-        // query).  Kept out of the main loop: one tree walk per tied vertex.
+        // query).  Kept out of the main loop: one tree walk per tied vertex.  One pass serves all the
+        // tied queries of the block (next to the axis of a 1M-vertex torus most queries of a block are tied,
+        // with hundreds of vertices each: a pass per query was 1.75 of the kernel's 3.0 ms there).
+        bool tie[HEAVY_Q], any_tie = false;
+        uint32_t hh[HEAVY_Q];
 #pragma unroll
         for (int j = 0; j < HEAVY_Q; ++j) {
-            if (!(s2[j] == b[j] && h[j] != H_NONE && !M.fast)) continue;
-            uint32_t hh = H_NONE;
+            tie[j] = s2[j] == b[j] && h[j] != H_NONE && !M.fast;  // (block-uniform)
+            any_tie = any_tie || tie[j];
+            hh[j] = H_NONE;
+        }
+        if (any_tie) {
             for (uint32_t k0 = 0; k0 < M.kd_npos; k0 += 4u * STEP) {
-                uint32_t du[4];
+                float4 P[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t k = k0 + STEP * u + threadIdx.x;
-                    const float4 P = M.kd_pts4[k < M.kd_npos ? k : M.kd_npos - 1];
-                    const float dx = p[j].x - P.x, dy = p[j].y - P.y, dz = p[j].z - P.z;
-                    du[u] = k < M.kd_npos ? __float_as_uint((dx * dx + dy * dy) + dz * dz) : 0xFFFFFFFFu;
+                    P[u] = M.kd_pts4[k < M.kd_npos ? k : M.kd_npos - 1];
                 }
-                if (__ballot(du[0] == b[j] || du[1] == b[j] || du[2] == b[j] || du[3] == b[j]) == 0ull) continue;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t k = k0 + STEP * u + threadIdx.x;
-                    if (du[u] == b[j])
-                        hh = hh == H_NONE ? k : (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)hh, (int)k);
+#pragma unroll
+                    for (int j = 0; j < HEAVY_Q; ++j) {
+                        if (!tie[j]) continue;
+                        const float dx = p[j].x - P[u].x, dy = p[j].y - P[u].y, dz = p[j].z - P[u].z;
+                        const uint32_t du = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+                        if (k < M.kd_npos && du == b[j])
+                            hh[j] = hh[j] == H_NONE ? k : (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)hh[j], (int)k);
+                    }
                 }
             }
-            for (int o = 32; o >= 1; o >>= 1) {
-                const uint32_t oh = __shfl_xor(hh, o);
-                if (hh == H_NONE)
-                    hh = oh;
-                else if (oh != H_NONE)
-                    hh = (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)hh, (int)oh);
+#pragma unroll
+            for (int j = 0; j < HEAVY_Q; ++j) {
+                if (!tie[j]) continue;
+                uint32_t x = hh[j];
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const uint32_t oh = __shfl_xor(x, o);
+                    if (x == H_NONE)
+                        x = oh;
+                    else if (oh != H_NONE)
+                        x = (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)x, (int)oh);
+                }
+                if (lane == 0) sh[wave][j] = x;
             }
-            if (lane == 0) sh[wave][j] = hh;
             __syncthreads();
-            hh = sh[0][j];
-            for (int w = 1; w < WAVES; ++w) {
-                const uint32_t oh = sh[w][j];
-                if (hh == H_NONE)
-                    hh = oh;
-                else if (oh != H_NONE)
-                    hh = (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)hh, (int)oh);
+#pragma unroll
+            for (int j = 0; j < HEAVY_Q; ++j) {
+                if (!tie[j]) continue;
+                uint32_t x = sh[0][j];
+                for (int w = 1; w < WAVES; ++w) {
+                    const uint32_t oh = sh[w][j];
+                    if (x == H_NONE)
+                        x = oh;
+                    else if (oh != H_NONE)
+                        x = (uint32_t)kd_dfs_first(M, p[j].x, p[j].y, p[j].z, (int)x, (int)oh);
+                }
+                h[j] = x;
             }
-            h[j] = hh;
             __syncthreads();
         }
         // thread j of the block finishes query j
