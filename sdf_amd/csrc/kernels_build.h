@@ -68,7 +68,7 @@ static inline float ord2f_host(uint32_t u) {
 }
 __global__ void k_bounds_init(uint32_t* b) {
     if (threadIdx.x < 3) b[threadIdx.x] = 0xFFFFFFFFu;
-    else if (threadIdx.x < 6) b[threadIdx.x] = 0u;
+    else if (threadIdx.x < 8) b[threadIdx.x] = 0u;  // ([6]: far queries of the launch, counted by k_query_morton)
 }
 // flat float view of the [n,3] points: thread-contiguous float4 loads (coordinate = index % 3).
 // Base pointers from hipMalloc / torch are 16-byte aligned, but a slice (pts[1:], a shard that starts
@@ -147,6 +147,10 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, i
 // (x', y') over the column grid's range.  The z+ / z- rays of a query read the face list of its column, so
 // the queries of one wave then share a handful of lists instead of reading 64 (the lists of a rough mesh
 // are 2 KB each: the 3-D order moved 6 TB/s for them).  r0, r1: rows of R giving x', y'.
+// far queries of a batch (kernels_packet.h, k_query_packet_far): centre and squared radius of the near region
+struct FarKey {
+    float c[3], r2;  // r2 == 0: off
+};
 struct ColumnKey {
     int on;
     float r0[3], r1[3];
@@ -155,8 +159,9 @@ struct ColumnKey {
 // One radix-sort tile per block (element (k, t) = base + k * 256 + t as in radix_sort.h): the keys, and the
 // tile's digit histogram of the first sort pass (what k_rs_hist would read the keys again for).
 __global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __restrict__ pts, uint32_t n,
-                                                             const uint32_t* __restrict__ b, uint32_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ hist, uint32_t ntiles, ColumnKey CK, int key_shift) {
+                                                             uint32_t* __restrict__ b, uint32_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ hist, uint32_t ntiles, ColumnKey CK, int key_shift,
+                                                             FarKey FK) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     float lo[3] = {0.f, 0.f, 0.f}, inv[3] = {0.f, 0.f, 0.f};
@@ -166,6 +171,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __rest
             const float ext = ord2f(b[3 + d]) - lo[d];
             inv[d] = ext > 0.f ? 1024.f / ext : 0.f;
         }
+    // Far queries (FarKey): when the batch reaches beyond the near box of the mesh, far queries sort behind the near
+    // ones — top key bit — by distance shell (3 bits) and direction (Morton code of the unit vector), and the near
+    // ones by their Morton code over the near box instead of the batch's bounds (which may be hundreds of meshes wide).
+    bool far_on = false;
+    uint32_t nfar = 0;
+    if (!CK.on && FK.r2 > 0.f) {
+        const float rf = __builtin_sqrtf(FK.r2);
+        for (int d = 0; d < 3; ++d) far_on = far_on || !(ord2f(b[d]) >= FK.c[d] - rf) || !(ord2f(b[3 + d]) <= FK.c[d] + rf);
+        if (far_on)
+            for (int d = 0; d < 3; ++d) lo[d] = FK.c[d] - rf, inv[d] = 512.f / rf;
+    }
     __syncthreads();
     const uint32_t base = blockIdx.x * RS_TILE;
     float x[RS_ITEMS], y[RS_ITEMS], z[RS_ITEMS];
@@ -189,6 +205,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __rest
                 key = expand16((uint32_t)fx) | (expand16((uint32_t)fy) << 1);
             } else {
                 key = morton30(x[k], y[k], z[k], lo, inv) >> key_shift;
+                if (far_on) {
+                    const uint32_t sh = far_shell(FK.c, FK.r2, x[k], y[k], z[k]);
+                    key >>= 1;  // near: the top bit stays clear
+                    if (sh) {
+                        ++nfar;
+                        const float dx = x[k] - FK.c[0], dy = y[k] - FK.c[1], dz = z[k] - FK.c[2];
+                        const float iv = 1.f / __builtin_sqrtf(__builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz)));
+                        const float l1[3] = {-1.f, -1.f, -1.f}, i1[3] = {511.5f, 511.5f, 511.5f};
+                        const uint32_t dm = morton30(dx * iv, dy * iv, dz * iv, l1, i1);  // 30 bits
+                        const int kb = 30 - key_shift;                                     // key bits
+                        key = (1u << (kb - 1)) | ((sh & 7u) << (kb - 4)) | (dm >> (34 - kb));
+                    }
+                }
             }
             keys[i] = key;
             atomicAdd(&h[key & 255u], 1u);
@@ -196,6 +225,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __rest
     }
     __syncthreads();
     hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+    if (far_on) {  // how many queries sort into the far part: the far kernel's blocks beyond it leave at once
+        for (int o = 32; o >= 1; o >>= 1) nfar += __shfl_xor(nfar, o);
+        if ((threadIdx.x & 63u) == 0u && nfar) atomicAdd((uint32_t*)b + 6, nfar);
+    }
 }
 
 // =========================================================================================

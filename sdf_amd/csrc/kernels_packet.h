@@ -1000,6 +1000,24 @@ __device__ __forceinline__ void packet_finish(const MeshDev& M, V3 p, bool valid
 // M.heavy_budget (odd: hand over to the cooperative kernel at that budget; the host sets it per launch),
 // the counter is the word after the heavy counter and the two pointers sit in device memory behind
 // it (CoopDesc at heavy_cnt + 2, written once by the host), read only by the waves that hand over.
+// ---- far packets (see k_query_packet_far below) ----
+// distance shell of a query: 0 = not far (or not finite), else 1 + floor(log2(D / R_far)) capped at 7
+__device__ __forceinline__ uint32_t far_shell(const float c[3], float r2, float x, float y, float z) {
+    const float dx = x - c[0], dy = y - c[1], dz = z - c[2];
+    const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+    if (!(d2 > r2) || !(d2 <= FLT_MAX) || !(r2 > 0.f)) return 0u;
+    const uint32_t e = ((__float_as_uint(d2 / r2) >> 23) & 255u) - 127u;  // floor(log2(D^2 / R^2)) >= 0
+    return 1u + min(e >> 1, 6u);
+}
+// wave-uniform: packet `pkt` of a launch of n queries lies in the far part of the sorted order as the key kernel
+// counted it (none, when the key kernel saw no reason to sort far queries apart), within the far kernel's range, and
+// every lane's query is far and of the same shell (lanes past the end repeat the last query)
+__device__ __forceinline__ bool far_packet(const MeshDev& M, float x, float y, float z, int64_t pkt, int64_t n) {
+    if (pkt < (int64_t)M.far_lo || 64 * pkt < n - (int64_t)*M.far_cnt) return false;
+    const uint32_t sh = far_shell(M.far_c, M.far_r2, x, y, z);
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh);
+    return s0 != 0u && __ballot(sh != s0) == 0ull;
+}
 #ifndef SDFK_COOP_WAVES
 #define SDFK_COOP_WAVES 8
 #endif
@@ -1038,6 +1056,8 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
         if ((threadIdx.x & 63) == 0) amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
         return;
     }
+    // (far packets of the covered range: k_query_packet_far walks them, launched behind this kernel)
+    if (M.far_r2 > 0.f && far_packet(M, p.x, p.y, p.z, i >> 6, n)) return;
     PacketBest pb;
     ExactState SE = {0x7F7FFFFFu, 0x7F7FFFFFu, H_NONE, 0xFFFFFFFFu};  // FLT_MAX bits (KNNResultSet::init)
     const float INF = __builtin_inff();
@@ -1074,6 +1094,231 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
         } else {
             packet_to_heavy(valid, i, src, off, amb_mask, amb_cnt, heavy_list, heavy_cnt);
         }
+        return;
+    }
+    packet_finish<KIND, ROBUST, APPROX>(M, p, valid, i, src, sign, pb, A, trunc_aabb, out, amb_mask, amb_cnt, off,
+                                        heavy_list, heavy_cnt);
+}
+
+// =========================================================================================
+// Far packets.  A batch spread over a region much larger than the mesh is sparse in space — 64 Morton-adjacent
+// queries of 8M in a box 300 x the mesh span several mesh diameters, every group is a candidate for some lane and
+// the walk above is useless (such packets went to the strict kernel, one tree walk per lane: 6 ns per query) — but
+// dense in DIRECTION: the same 64 queries, sorted by the direction they see the mesh from, lie within 0.01 rad, and
+// what a far query can have nearest is the cap of the mesh facing it.  The key kernel (k_query_morton) therefore
+// sorts far queries (farther than sqrt(M.far_r2) from the mesh centre) behind the near ones, by distance shell
+// (powers of two) and direction; waves whose queries are all far and of one shell are left alone by the main
+// kernel and walked here, with bounds made for them:
+//   for ANY origin o and the unit vector d_l from o to q_l:   |q_l - x|  >=  d_l.(q_l - x)  =  D_l - d_l.(x - o),
+//   D_l = |q_l - o|, so a box B can be skipped for lane l when  D_l - sup_B(d_l) > rr_l  (rr_l: the lane's
+//   threshold as a distance), with sup_B(d) = max_{x in B} d.(x - o) <= d.c' + sum_a |d.R_a| h_a  (c' = c_B - o).
+// o is the centre of the first evaluated group's box (then rr_l - D_l is within the cap's depth of 0 for every
+// lane, however far the queries are and however they are spread along their common direction), and with the
+// packet's mean direction a, delta_l = |d_l - a| <= theta:
+//   lane level     -(d_l.c' + supH + delta_l h1) > rr_l - D_l        supH = sum_a |a.R_a| h_a, h1 = sum_a h_a
+//   packet level   -(a.c' + supH) - theta (|c'| + h1) > max_l (rr_l - D_l)
+// — five readlanes and five VALU per candidate.  Everything else (approximate evaluation, the four group minima,
+// second phase, near-tie decision) is the main kernel's.  Rounding: d_l is a unit vector within 4u, D_l is
+// rounded down and rr_l up, projections carry <= 8u (|c'| + h1): slack 2^-19 (|c'| + h1) per test.
+// =========================================================================================
+struct FarLane {
+    float cx, cy, cz;  // c' = c_B - o
+    float supH, h1;    // sum_a |a.R_a| h_a, sum_a h_a
+    float sl;          // slack of one test: 2^-19 (|c'| + h1)
+    float pk;          // packet-level bound
+    uint32_t tag;
+};
+__device__ __forceinline__ FarLane far_wide(const float4* __restrict__ rec, uint32_t lane, float ox, float oy, float oz,
+                                            float ax, float ay, float az, float theta) {
+    const float4 A = rec[lane], B = rec[64u + lane], C = rec[128u + lane], D = rec[192u + lane];
+    FarLane o;
+    o.cx = A.x - ox, o.cy = A.y - oy, o.cz = A.z - oz;
+    const float p0 = fabsf(__builtin_fmaf(B.x, ax, __builtin_fmaf(B.y, ay, B.z * az)));
+    const float p1 = fabsf(__builtin_fmaf(C.x, ax, __builtin_fmaf(C.y, ay, C.z * az)));
+    const float p2 = fabsf(__builtin_fmaf(D.x, ax, __builtin_fmaf(D.y, ay, D.z * az)));
+    o.h1 = (A.w + B.w) + C.w;
+    o.supH = __builtin_fmaf(A.w, p0, __builtin_fmaf(B.w, p1, C.w * p2));
+    const float cn = __builtin_amdgcn_sqrtf(__builtin_fmaf(o.cx, o.cx, __builtin_fmaf(o.cy, o.cy, o.cz * o.cz))) + o.h1;
+    const float sa = __builtin_fmaf(ax, o.cx, __builtin_fmaf(ay, o.cy, az * o.cz));
+    o.sl = 1.9073486e-6f * cn;
+    o.pk = -(sa + o.supH) - __builtin_fmaf(theta, cn, o.sl);
+    o.tag = __float_as_uint(D.w);
+    return o;
+}
+// the packet's frame about the origin o: per lane D (rounded down), unit direction d, delta = |d - a| (rounded up);
+// wave-uniform: the mean direction a and theta = max delta
+struct FarFrame {
+    float D, dx, dy, dz, delta;
+    float ax, ay, az, theta;
+};
+__device__ __forceinline__ FarFrame far_frame(float qx, float qy, float qz, float ox, float oy, float oz) {
+    FarFrame F;
+    const float tx = qx - ox, ty = qy - oy, tz = qz - oz;
+    const float D = __builtin_sqrtf(__builtin_fmaf(tx, tx, __builtin_fmaf(ty, ty, tz * tz)));
+    const float inv = 1.f / D;
+    F.dx = tx * inv, F.dy = ty * inv, F.dz = tz * inv;
+    F.D = D - D * 2.3841858e-7f;
+    const float mx = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(F.dx))) + pk_ord2f(wave_umax(pk_f2ord(F.dx))));
+    const float my = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(F.dy))) + pk_ord2f(wave_umax(pk_f2ord(F.dy))));
+    const float mz = 0.5f * (pk_ord2f(wave_umin(pk_f2ord(F.dz))) + pk_ord2f(wave_umax(pk_f2ord(F.dz))));
+    const float mi = 1.f / __builtin_sqrtf(__builtin_fmaf(mx, mx, __builtin_fmaf(my, my, mz * mz)));
+    F.ax = mx * mi, F.ay = my * mi, F.az = mz * mi;
+    if (!(fabsf(F.ax) <= 2.f && fabsf(F.ay) <= 2.f && fabsf(F.az) <= 2.f)) F.ax = 1.f, F.ay = 0.f, F.az = 0.f;  // (opposite directions: any axis)
+    const float ex = F.dx - F.ax, ey = F.dy - F.ay, ez = F.dz - F.az;
+    F.delta = __builtin_sqrtf(__builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez))) * (1.f + 4.7683716e-7f) + 2.3841858e-7f;
+    F.theta = __uint_as_float(wave_umax(__float_as_uint(F.delta)));  // (non-negative; NaN -> large)
+    return F;
+}
+
+// the walk of a far packet (approximate pass); returns 1 when the wave gave up on its work budget
+template <bool APPROX>
+__device__ __forceinline__ uint32_t packet_walk_far(const MeshDev& M, float qx, float qy, float qz, float cm,
+                                                ExactState& SE, ApproxState& SA, uint32_t budget) {
+    const uint32_t lane = threadIdx.x & 63u;
+    SDFK_COUNT(0, 1);
+    if (M.kd_ngroups == 0u) return 0u;
+    const uint32_t nrows = (M.kd_nl1 + 63u) >> 6;
+    uint32_t work = 0;
+    // ---- greedy: seen from the mesh centre, the L1 node and then the group reaching farthest towards the packet
+    uint32_t j0, g0;
+    float ox = M.far_c[0], oy = M.far_c[1], oz = M.far_c[2];
+    {
+        const FarFrame F0 = far_frame(qx, qy, qz, ox, oy, oz);
+        uint32_t bkey = 0xFFFFFFFFu, brow = 0u;
+        for (uint32_t row = 0; row < nrows; ++row) {
+            const FarLane o = far_wide(M.kd_l1obb + 256u * (size_t)row, lane, ox, oy, oz, F0.ax, F0.ay, F0.az, 0.f);
+            const uint32_t key = 64u * row + lane < M.kd_nl1 ? (o.pk == o.pk ? pk_f2ord(o.pk) : 0u) : 0xFFFFFFFFu;
+            if (key < bkey) bkey = key, brow = row;
+        }
+        SDFK_COUNT(1, nrows);
+        const uint32_t mkey = wave_umin(bkey);
+        const uint32_t who = (uint32_t)__builtin_ctzll(__ballot(bkey == mkey));
+        j0 = 64u * (uint32_t)__builtin_amdgcn_readlane((int)brow, (int)who) + who;
+        const uint32_t cnt = min(64u, M.kd_ngroups - 64u * j0);
+        const FarLane o = far_wide(M.kd_gobb + 256u * (size_t)j0, lane, ox, oy, oz, F0.ax, F0.ay, F0.az, 0.f);
+        SDFK_COUNT(1, 1);
+        const uint32_t key = lane < cnt ? (o.pk == o.pk ? pk_f2ord(o.pk) : 0u) : 0xFFFFFFFFu;
+        const uint32_t mk = wave_umin(key);
+        g0 = (uint32_t)__builtin_ctzll(__ballot(key == mk));
+        const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)o.tag, (int)g0);
+        SDFK_COUNT(2, 1);
+        SDFK_COUNT(3, ref & 15u);
+        work += ref & 15u;
+        if (APPROX)
+            group_approx<false>(M, qx, qy, qz, ref, SA);
+        else
+            group_exact(M, qx, qy, qz, ref, SE);
+        // the origin of everything below: the centre of that group's box (a box that contains everything has centre 0)
+        ox = wave_readf(o.cx, g0) + ox, oy = wave_readf(o.cy, g0) + oy, oz = wave_readf(o.cz, g0) + oz;
+        if (!(fabsf(ox) <= FLT_MAX && fabsf(oy) <= FLT_MAX && fabsf(oz) <= FLT_MAX)) ox = M.far_c[0], oy = M.far_c[1], oz = M.far_c[2];
+    }
+    const FarFrame F = far_frame(qx, qy, qz, ox, oy, oz);
+    float marg;  // per lane: rr_l - D_l (threshold distance, rounded up, minus the distance to o, rounded down)
+#define SDFK_FAR_REFRESH() \
+    marg = __builtin_amdgcn_sqrtf(APPROX ? apx_upper(M, SA.B1) * cm : __uint_as_float(SE.b) * cm) * (1.f + 4.7683716e-7f) - F.D;
+#define SDFK_FAR_RES() pk_ord2f(wave_umax(pk_f2ord(marg)))
+    SDFK_FAR_REFRESH()
+    float res = SDFK_FAR_RES();
+    // candidates of one wide test, deepest towards the packet first
+#define SDFK_FAR_CANDS(O, ALIVE)                                                                                  \
+    for (;;) {                                                                                                    \
+        const uint32_t key_ = (ALIVE) ? ((O).pk == (O).pk ? pk_f2ord((O).pk) : 0u) : 0xFFFFFFFFu;                \
+        const uint32_t mk_ = wave_umin(key_);                                                                     \
+        if (mk_ == 0xFFFFFFFFu || (mk_ != 0u && pk_ord2f(mk_) > res)) break;                                      \
+        const uint32_t g_ = (uint32_t)__builtin_ctzll(__ballot(key_ == mk_));                                     \
+        if (lane == g_) ALIVE = false;                                                                            \
+        SDFK_COUNT(5, 1);                                                                                         \
+        ++work;                                                                                                   \
+        const float cn_ = wave_readf((O).h1, g_);                                                                 \
+        const float t_ = -(__builtin_fmaf(F.dx, wave_readf((O).cx, g_),                                           \
+                                          __builtin_fmaf(F.dy, wave_readf((O).cy, g_), F.dz * wave_readf((O).cz, g_))) + \
+                           __builtin_fmaf(F.delta, cn_, wave_readf((O).supH, g_)));                               \
+        if (__ballot(!(t_ - wave_readf((O).sl, g_) > marg)) == 0ull) continue;                                    \
+        const uint32_t ref_ = (uint32_t)__builtin_amdgcn_readlane((int)(O).tag, (int)g_);                         \
+        SDFK_COUNT(2, 1);                                                                                         \
+        SDFK_COUNT(3, ref_ & 15u);                                                                                \
+        work += ref_ & 15u;                                                                                       \
+        {                                                                                                         \
+            const uint32_t old_ = APPROX ? __float_as_uint(SA.B1) : SE.b;                                         \
+            if (APPROX)                                                                                           \
+                group_approx<false>(M, qx, qy, qz, ref_, SA);                                                     \
+            else                                                                                                  \
+                group_exact(M, qx, qy, qz, ref_, SE);                                                             \
+            if (__ballot((APPROX ? __float_as_uint(SA.B1) : SE.b) != old_) != 0ull) {                             \
+                SDFK_FAR_REFRESH()                                                                                \
+                res = SDFK_FAR_RES();                                                                             \
+            }                                                                                                     \
+        }                                                                                                         \
+        if (work > budget) return 1u;                                                                             \
+    }
+    for (uint32_t row = 0; row < nrows; ++row) {
+        const FarLane o1 = far_wide(M.kd_l1obb + 256u * (size_t)row, lane, ox, oy, oz, F.ax, F.ay, F.az, F.theta);
+        SDFK_COUNT(1, 1);
+        bool alive1 = 64u * row + lane < M.kd_nl1 && !(o1.pk > res);
+        for (;;) {
+            const uint32_t key = alive1 ? (o1.pk == o1.pk ? pk_f2ord(o1.pk) : 0u) : 0xFFFFFFFFu;
+            const uint32_t mk = wave_umin(key);
+            if (mk == 0xFFFFFFFFu || (mk != 0u && pk_ord2f(mk) > res)) break;
+            const uint32_t k = (uint32_t)__builtin_ctzll(__ballot(key == mk));
+            if (lane == k) alive1 = false;
+            const uint32_t j = 64u * row + k;
+            const uint32_t cnt = min(64u, M.kd_ngroups - 64u * j);
+            const FarLane o = far_wide(M.kd_gobb + 256u * (size_t)j, lane, ox, oy, oz, F.ax, F.ay, F.az, F.theta);
+            SDFK_COUNT(1, 1);
+            ++work;
+            bool alive = lane < cnt && !(o.pk > res) && !(j == j0 && lane == g0);
+            SDFK_FAR_CANDS(o, alive)
+        }
+    }
+#undef SDFK_FAR_CANDS
+#undef SDFK_FAR_RES
+#undef SDFK_FAR_REFRESH
+    return 0u;
+}
+
+// One far packet per wave, taken from the END of the sorted order (the far queries sort last): block b walks
+// packet npk - 1 - b if that packet is a far packet, and leaves otherwise — as the main kernel leaves every far
+// packet from M.far_lo on to this one.  Launched with min(npk, FAR_CAP) blocks behind the main kernel.
+// far_cnt: the far queries of the launch as the key kernel counted them (they hold the last sorted positions): blocks
+// whose packets lie before them leave at once — a launch without far queries pays FAR_CAP / 4 empty blocks.
+constexpr uint32_t FAR_CAP = 1u << 19;  // packets (32M far queries of one launch; more: the rest takes the old way)
+#ifndef SDFK_FAR_BLOCK
+#define SDFK_FAR_BLOCK 256
+#endif
+constexpr int FAR_BLOCK = SDFK_FAR_BLOCK;  // (256: four packets per block)
+template <int KIND, bool ROBUST, bool APPROX>
+__global__ __launch_bounds__(FAR_BLOCK) SDFK_PK_SGPR void k_query_packet_far(MeshDev M, const float* __restrict__ pts,
+                                                             const uint32_t* __restrict__ perm, int64_t n,
+                                                             int trunc_aabb, void* __restrict__ out,
+                                                             unsigned long long* __restrict__ amb_mask,
+                                                             uint32_t* __restrict__ amb_cnt, uint32_t off,
+                                                             uint32_t* __restrict__ heavy_list,
+                                                             uint32_t* __restrict__ heavy_cnt) {
+    const int64_t npk = (n + 63) >> 6;
+    const int64_t nfar = (int64_t)*M.far_cnt;
+    if ((int64_t)blockIdx.x * (FAR_BLOCK / 64) * 64 >= nfar + 64) return;  // block-uniform (+ the packet straddling the boundary)
+    const int64_t pkt = npk - 1 - ((int64_t)blockIdx.x * (FAR_BLOCK / 64) + (int64_t)(threadIdx.x >> 6));
+    if (pkt < 0) return;
+    const int64_t i = pkt * 64 + (int64_t)(threadIdx.x & 63u);
+    const bool valid = i < n;
+    const int64_t ic = valid ? i : n - 1;
+    const int64_t src = (int64_t)SDFK_NT_LOAD(&perm[ic]);
+    const V3 p = {SDFK_NT_LOAD(&pts[3 * src]), SDFK_NT_LOAD(&pts[3 * src + 1]), SDFK_NT_LOAD(&pts[3 * src + 2])};
+    if (!far_packet(M, p.x, p.y, p.z, pkt, n)) return;  // wave-uniform: the main kernel has it
+    float sign = 0.f;
+    if (ROBUST && KIND != Q_NN) sign = raycast_packet(M, p, valid);  // sdf.cpp:110
+    PacketBest pb;
+    ExactState SE = {0x7F7FFFFFu, 0x7F7FFFFFu, H_NONE, 0xFFFFFFFFu};
+    const float INF = __builtin_inff();
+    ApproxState A = {INF, INF, INF, INF, H_NONE, H_NONE, H_NONE};
+    const uint32_t wr = packet_walk_far<APPROX>(M, p.x, p.y, p.z, M.amb_c2, SE, A, M.heavy_budget);
+    if (!APPROX) {
+        if (SE.b == SE.tieb) SE.s2 = SE.b;  // a settled exact tie is a tie
+        pb.b = __uint_as_float(SE.b), pb.s = __uint_as_float(SE.s2), pb.h = SE.h;
+    }
+    pb.bailed = wr == 1u;
+    if (pb.bailed) {
+        packet_to_heavy(valid, i, src, off, amb_mask, amb_cnt, heavy_list, heavy_cnt);
         return;
     }
     packet_finish<KIND, ROBUST, APPROX>(M, p, valid, i, src, sign, pb, A, trunc_aabb, out, amb_mask, amb_cnt, off,

@@ -46,6 +46,12 @@ struct MeshDev {
     const float4* kd_apx4;
     const float4* kd_actr;
     float apx_k1, apx_e0;
+    // far packets (kernels_packet.h, k_query_packet_far): queries farther than sqrt(far_r2) from far_c (the centre of
+    // the mesh AABB) are "far"; far_r2 == 0: no far kernel behind this launch.  far_lo: first packet of the launch
+    // the far kernel covers (it takes the packets from the end of the sorted order).
+    float far_c[3], far_r2;
+    uint32_t far_lo;
+    const uint32_t* far_cnt;  // far queries of the launch (they hold the last sorted positions), counted by the key kernel
     // adjacency + face geometry
     const uint32_t* adj_off;
     const int32_t* adj_faces;

@@ -214,6 +214,8 @@ struct sdfhip_ctx {
     int64_t opt_cube_lists = -1;   // packet pass, cube lists: -1 automatic (launches of >= opt_cube_min points), 0 off, 1 on
     int64_t opt_cube_min = 8 << 20;
     int64_t opt_cube_level = 0;    // cubes per axis = 2^level; 0 automatic (~4096 queries per cube)
+    int64_t opt_far = 1;      // packet pass: far packets (k_query_packet_far); option "far_packets"
+    int64_t opt_far_x10 = 60; // ... from this many tenths of the mesh's half diagonal on; option "far_radius_x10"
     int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
     bool approx_ok = false;   // decided by every update(): see approx_pays()
     bool approx_pre = false;  // ... its value when the tree was uploaded (fill_apx may still turn it off; read by followers)
@@ -974,6 +976,21 @@ int do_update(sdfhip_ctx* h, bool draw_R, UpdateSync* sync = nullptr) {
     return 0;
 }
 
+// far packets (kernels_packet.h): squared radius of the near region — six half diagonals of the mesh AABB around its
+// centre (8M points in a box +-4 / +-8 / +-30 around the unit torus, nn: 2 half diagonals 14.2 / 10.6 / 6.3 ms, 4.5: 4.4 / 7.3 /
+// 6.7, 6: 4.25 / 6.9 / 6.9, 9: 4.2 / 6.2 / 8.8; closer in, the cap facing a query is too large for this walk); 0: no far packets
+float far_radius2(const sdfhip_ctx* h) {
+    double r2 = 0.0;
+    for (int d = 0; d < 3; ++d) {
+        const double e = 0.5 * ((double)h->aabb[d + 3] - (double)h->aabb[d]);
+        r2 += e * e;
+        if (!std::isfinite(0.5 * ((double)h->aabb[d + 3] + (double)h->aabb[d]))) return 0.f;
+    }
+    const double k = 0.1 * (double)h->opt_far_x10;
+    const float f = (float)(k * k * r2);
+    return h->opt_far && f > 0.f && f < 1e30f ? f : 0.f;
+}
+
 MeshDev mesh_view(const sdfhip_ctx* h) {
     MeshDev M;
     M.kd_pn = h->d_kd_pn;
@@ -998,6 +1015,8 @@ MeshDev mesh_view(const sdfhip_ctx* h) {
     M.kd_lbox = h->d_kd_lbox;
     M.kd_actr = h->d_kd_actr;
     M.apx_k1 = h->apx_k1, M.apx_e0 = h->apx_e0;
+    for (int d = 0; d < 3; ++d) M.far_c[d] = M.obb_cm[d];
+    M.far_r2 = 0.f, M.far_lo = 0u, M.far_cnt = nullptr;  // (far packets: set per launch, run_query_t)
     M.kd_npos = h->fast_active ? (uint32_t)(FAST_GROUP * ((h->nv + FAST_GROUP - 1) / FAST_GROUP))
                                : h->kd_npos;
     // a wave may walk 1/8 of the tree (4 positions per chunk) before it hands its queries over
@@ -1275,6 +1294,10 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
         deferred_pts = 0;
         return 0;
     };
+    // far packets: sorted launches of the packet pass (not the static scratch: its sizes are small and its callers near
+    // the mesh)
+    const float far_r2 = far_radius2(h);
+    const bool far_ok = packet_any && !W.fixed && far_r2 > 0.f && !(KIND == Q_CONTAINS && ROBUST);
     for (int64_t off = 0; off < n; off += chunk) {
         const int64_t m = (n - off) < chunk ? (n - off) : chunk;
         const float* p = d_pts + 3 * off;
@@ -1299,7 +1322,10 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             if (int rc = W.sorter.reserve((uint32_t)m)) return rc;  // (the key kernel fills its first histogram)
             const uint32_t ntiles = (uint32_t)((m + RS_TILE - 1) / RS_TILE);
             const int key_bits = CK.on ? 24 : (int)h->opt_sort_bits;
-            k_query_morton<<<ntiles, RS_THREADS, 0, s>>>(p, (uint32_t)m, W.qbounds, W.qkeys, W.sorter.hist, ntiles, CK, 30 - key_bits);
+            // far queries sort behind the near ones, by direction, when the packet pass will walk them as far packets
+            FarKey FK = {{M.far_c[0], M.far_c[1], M.far_c[2]}, 0.f};
+            if (far_ok && !CK.on) FK.r2 = far_r2;
+            k_query_morton<<<ntiles, RS_THREADS, 0, s>>>(p, (uint32_t)m, W.qbounds, W.qkeys, W.sorter.hist, ntiles, CK, 30 - key_bits, FK);
             uint32_t* sorted_perm = nullptr;
             if (int rc = W.sorter.sort(W.qkeys, W.qperm, (uint32_t)m, key_bits, 1, s, nullptr, &sorted_perm, false, true))
                 return rc;
@@ -1332,6 +1358,9 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
                 coop_budget = std::min<uint32_t>(coop_budget, (uint32_t)std::max<int64_t>(300, 1500 * m >> 20));
             MeshDev Mm = M;  // the main kernel's view: its budget, and in the low bit who takes over beyond it
             Mm.heavy_budget = coop ? (coop_budget | 1u) : (M.heavy_budget & ~1u);
+            const int64_t npk_all = (m + 63) / 64;
+            const bool far_run = far_ok && perm != nullptr;
+            if (far_run) Mm.far_r2 = far_r2, Mm.far_lo = (uint32_t)std::max<int64_t>(0, npk_all - (int64_t)FAR_CAP), Mm.far_cnt = W.qbounds + 6;
             // Cube lists (kernels_packet.h, k_cube_lists): the sorted launch's query domain is cut into nc^3 cubes of
             // ~4096 queries; one wave per cube lists the groups its queries can need and the packet waves test that
             // list instead of walking the boxes from the top.  It pays when a cube is small against the mesh (short
@@ -1370,6 +1399,13 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
                     Mm, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off,
                     W.fb_list + W.fb_cap, W.fb_count + 2);
             if (int rc = prof.end(m)) return rc;  // (the dominant kernel alone: what rocprofv3 lists under its name)
+            if (far_run) {  // the far packets the main kernel left alone (from the end of the sorted order)
+                MeshDev Mf = Mm;
+                Mf.heavy_budget = M.heavy_budget;
+                const int64_t fpk = std::min<int64_t>(npk_all, (int64_t)FAR_CAP);
+                k_query_packet_far<PK, ROBUST, false><<<(uint32_t)((fpk + FAR_BLOCK / 64 - 1) / (FAR_BLOCK / 64)), FAR_BLOCK, 0, s>>>(
+                    Mf, p, perm, m, trunc, o, W.amb_mask, W.amb_cnt, (uint32_t)off, W.fb_list + W.fb_cap, W.fb_count + 2);
+            }
             if (coop) {
                 const int64_t npk = (m + 63) / 64;
                 const CoopDesc CB = {W.coop_list, W.coop_state};
@@ -2220,6 +2256,10 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
     std::lock_guard<std::mutex> lk(h->mu);
     if (!strcmp(key, "sort_queries"))
         h->opt_sort = v;
+    else if (!strcmp(key, "far_packets"))
+        h->opt_far = v;
+    else if (!strcmp(key, "far_radius_x10"))
+        h->opt_far_x10 = v < 11 ? 11 : v;
     else if (!strcmp(key, "profile")) {
         h->opt_profile = v;
         if (v == 2) h->prof_ms = 0.0, h->prof_launches = 0, h->prof_points = 0;  // reset

@@ -606,19 +606,26 @@ def test_automatic_walk_choice_looks_at_local_vertex_density(monkeypatch):
     assert kinds["plain"] == 3 and kinds["fine part"] == 2, kinds  # SDFHIP_KERNEL_PACKET_APPROX / _EXACT
 
 
+@pytest.mark.parametrize("far_packets", [1, 0])
 @pytest.mark.parametrize("half, n", [(300.0, 400_000), (30.0, 2_000_000)])
-def test_batches_spread_far_beyond_the_mesh(half, n):
-    """Queries spread over a box 30 / 300 times the mesh: Morton packets as wide as the mesh go to the heavy list
-    unwalked (packet_walk), and a heavy list this long is answered by the strict kernel instead of the exact scan
-    (8M such points: 554 -> 50 ms).  Results must not notice."""
+def test_batches_spread_far_beyond_the_mesh(half, n, far_packets):
+    """Queries spread over a box 30 / 300 times the mesh.  far_packets=1 (default): far queries are sorted by the
+    direction they see the mesh from and walked as far packets (k_query_packet_far; 8M points in the +-300 box:
+    50 -> 7 ms), few are left to the lists.  far_packets=0, the way of round 2: Morton packets as wide as the mesh go
+    to the heavy list unwalked (packet_walk), and a heavy list this long is answered by the strict kernel instead of
+    the exact scan (554 -> 50 ms).  Results must not notice either."""
     v, f = meshes.torus(424, 424)
     R = meshes.random_rotation(11)
     s = SDF(v, f)
     s.set_raycast_axes(R)
     s.set_option("profile", 1)
+    s.set_option("far_packets", far_packets)
     o = po.OracleSDF(v, f, True, R)
     q = (np.random.default_rng(21).uniform(-1, 1, (n, 3)) * half).astype(np.float32)
     assert (s.nn(q) == o.nn(q)).all()
-    assert s.stats["last_heavy_points"] > 210_000  # (the strict kernel's share: above 4e10 / tree positions)
+    if far_packets:
+        assert s.stats["last_heavy_points"] < n // 50
+    else:
+        assert s.stats["last_heavy_points"] > 210_000  # (the strict kernel's share: above 4e10 / tree positions)
     assert same_float(s(q), o(q)).all()
     assert (s.contains(q) == o.contains(q)).all()
