@@ -331,7 +331,9 @@ __device__ __forceinline__ float apx_upper(const MeshDev& M, float est) {  // (N
     return fmaxf(fmaxf(x * (1.f + 8.f * 5.9604645e-8f), x), 0.f);
 }
 __device__ __forceinline__ float apx_lower(const MeshDev& M, float est) {
-    const float y = est - apx_err(M, est);
+    // (est = +inf — a lane that has met fewer than four groups — must stay +inf: inf - inf would be a NaN, which every
+    // window test reads as "inside": such lanes went to the exact scan as fourth-candidate queries)
+    const float y = est - fminf(apx_err(M, est), FLT_MAX);
     return fminf(y * (1.f - 8.f * 5.9604645e-8f), y);
 }
 

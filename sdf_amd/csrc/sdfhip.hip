@@ -798,6 +798,9 @@ int fill_apx(sdfhip_ctx* h, uint32_t ngroups, size_t nalloc) {
         if (!(lambda <= APPROX_LAMBDA_MAX)) h->approx_ok = false;
     }
     if (!h->apx_usable) h->approx_ok = false;
+    if (std::getenv("SDFHIP_DEBUG"))
+        std::fprintf(stderr, "[sdfhip] approximate pass: largest group radius^2 %.4g, e0 %.4g, usable %d, on %d\n", (double)r2,
+                     (double)h->apx_e0, (int)h->apx_usable, (int)h->approx_ok);
     return 0;
 }
 
