@@ -306,12 +306,16 @@ int sdfhip_host_free(void* p);
  * grid's cells), "grid_per_face" (list entries per face beyond which the grid coarsens), "x_grid" (0/1, applies at the next
  * update: the x+ tie-break ray reads its own column grid over (y', z') instead of walking the LBVH), "column_sort" (0/1: robust
  * contains() sorts its queries by column of the ray-cast frame instead of 3-D Morton order), "coop_budget" (work units after
- * which a packet's walk is continued by eight waves, 0 = never; default -1 = automatic: 1500, less for launches of < 1M points), "coop_max" (largest launch, in points, that
+ * which a packet's walk is continued by eight waves, 0 = never; default -1 = automatic: 1500 .. 6000 with the size of the tree,
+ * less for launches of < 1M points), "coop_max" (largest launch, in points, that
  * uses it; default 2^27 = every launch), "cube_lists" (packet pass: the query domain of a sorted launch is cut into cubes, one
  * wave per cube lists the vertex groups its queries can need and the packet waves test that list instead of walking the box
  * hierarchy from the top; -1 automatic (default: launches of >= "cube_min" points, default 2^23), 0 off, 1 on for every sorted
  * launch), "cube_level" (2^level cubes per axis; 0 = automatic, default: cube edge ~1.3 x the size of a vertex group),
- * "sort_bits" (Morton key bits of the query sort: 24 (default, three radix passes) or 30 (four)).
+ * "sort_bits" (Morton key bits of the query sort: 24 (default, three radix passes) or 30 (four)),
+ * "far_packets" (1, default: in a sorted launch that reaches beyond the near region of the mesh, queries farther than
+ * "far_radius_x10" tenths (default 60) of the half diagonal of the mesh's box from its centre are sorted by distance shell and
+ * direction and walked by a kernel of their own; 0: the strict kernel answers them, one tree walk per query).
  * No option changes a result, except "fast_nn" as described. */
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t value);
 
