@@ -47,7 +47,9 @@ constexpr int PBLOCK = SDFK_PBLOCK;
 #define SDFK_PK_NSGPR 96
 #endif
 #ifndef SDFK_PK_SGPR
-#ifdef SDFK_PK_NVGPR
+#ifdef SDFK_PK_WAVES
+#define SDFK_PK_SGPR __attribute__((amdgpu_num_sgpr(SDFK_PK_NSGPR), amdgpu_waves_per_eu(SDFK_PK_WAVES, SDFK_PK_WAVES)))
+#elif defined(SDFK_PK_NVGPR)
 #define SDFK_PK_SGPR __attribute__((amdgpu_num_sgpr(SDFK_PK_NSGPR), amdgpu_num_vgpr(SDFK_PK_NVGPR)))
 #else
 #define SDFK_PK_SGPR __attribute__((amdgpu_num_sgpr(SDFK_PK_NSGPR)))
@@ -1051,6 +1053,9 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
     // the point stream (and the results) pass through once: non-temporal, so that L2 keeps the trees
     const int64_t src = perm ? (int64_t)SDFK_NT_LOAD(&perm[ic]) : ic;
     const V3 p = {SDFK_NT_LOAD(&pts[3 * src]), SDFK_NT_LOAD(&pts[3 * src + 1]), SDFK_NT_LOAD(&pts[3 * src + 2])};
+    // (far packets of the covered range: k_query_packet_far walks them, launched behind this kernel; never set for
+    // robust contains)
+    if (M.far_r2 > 0.f && far_packet(M, p.x, p.y, p.z, i >> 6, n)) return;
     float sign = 0.f;
     if (ROBUST && KIND != Q_NN) sign = raycast_packet(M, p, valid);  // sdf.cpp:110
     if (ROBUST && KIND == Q_CONTAINS) {  // sdf.cpp:163-169: no nearest-vertex search at all
@@ -1058,8 +1063,6 @@ __global__ __launch_bounds__(PBLOCK) SDFK_PK_SGPR void k_query_packet(MeshDev M,
         if ((threadIdx.x & 63) == 0) amb_mask[i >> 6] = 0ull, amb_cnt[i >> 6] = 0u;
         return;
     }
-    // (far packets of the covered range: k_query_packet_far walks them, launched behind this kernel)
-    if (M.far_r2 > 0.f && far_packet(M, p.x, p.y, p.z, i >> 6, n)) return;
     PacketBest pb;
     ExactState SE = {0x7F7FFFFFu, 0x7F7FFFFFu, H_NONE, 0xFFFFFFFFu};  // FLT_MAX bits (KNNResultSet::init)
     const float INF = __builtin_inff();
