@@ -125,3 +125,28 @@ def test_far_packets_in_fast_nn_mode_follow_its_tie_rule():
     d2 = lambda a, b: ((a[:, 0] - b[:, 0]) ** 2 + (a[:, 1] - b[:, 1]) ** 2) + (a[:, 2] - b[:, 2]) ** 2  # fp32, reference order
     assert (d2(q, v[got]) <= d2(q, v[ref])).all()
     assert np.mean(d2(q, v[got]) == d2(q, v[ref])) > 0.999
+
+
+def test_far_packets_in_chunked_launches_and_in_a_group():
+    """several chunks per call (every chunk sorts, counts its far queries and launches its far kernel anew), with
+    30-bit sort keys; and the same batch through a two-member group on one device"""
+    import torch
+    from sdf_amd import GroupSDF
+    v, f = meshes.torus(120, 120)
+    R = meshes.random_rotation(9)
+    lo, hi = v.min(0).astype(np.float64), v.max(0).astype(np.float64)
+    q = _mixed_queries(np.random.default_rng(4), 0.5 * (lo + hi), 0.5 * float(np.linalg.norm(hi - lo)), 100_000)
+    o = po.OracleSDF(v, f, True, R)
+    want_nn, want = o.nn(q), o(q)
+    s = SDF(v, f, robust=True)
+    s.set_raycast_axes(R)
+    s.set_option("scan_max", 0)
+    s.set_option("chunk", 1 << 16)
+    s.set_option("sort_bits", 30)
+    qt = torch.from_numpy(q).cuda()
+    assert (s.nn(qt).cpu().numpy() == want_nn).all()
+    assert same_float(s(qt).cpu().numpy(), want).all()
+    g = GroupSDF(v, f, devices=[0, 0], robust=True)
+    g.set_raycast_axes(R)
+    assert (g.nn(q) == want_nn).all()
+    assert same_float(g(q), want).all()
