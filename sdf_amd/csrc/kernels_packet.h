@@ -64,6 +64,7 @@ struct PacketBest {
     float s;     // second smallest distance as a multiset (an exact tie shows as s == b); exact
                  // whenever it is <= b * c^2
     bool bailed;  // the wave exceeded its work budget: nothing is valid, see k_query_heavy
+    bool lazy_ties = false;  // h names the holder GROUP even when several of its vertices are at distance b (group_exact_lazy)
     uint32_t h;  // among the vertices at distance exactly b, the one nanoflann's near-first DFS
                  // (for THIS lane) meets first: its tree position, or (bit 31) the ref of the
                  // packet group in which it is the only vertex at that distance; H_NONE: none
@@ -313,6 +314,56 @@ __device__ __forceinline__ void group_exact(const MeshDev& M, float qx, float qy
     }
     S.b = b, S.s2 = s2, S.h = h;
 }
+
+// Exact evaluation with exact ties left for later (far packets: fp32 distances at 300 mesh sizes are quantised so
+// coarsely that ties are the rule — group_exact's redo, a sequential pass over the group for the whole wave whenever
+// some lane sees two equal smallest distances, ran 4.5 times per wave there, a third of the far kernel).  What the
+// finish needs is (b, s2 with s2 == b flagging a tie, h = the group holding the tied vertex nanoflann's DFS meets
+// first): s2 == b comes out of the fast path by itself; a strict improvement makes this group the holder; and a
+// group that does not improve b but holds a vertex AT b (one more compare per slot, against the b before the group)
+// ties with the holder across groups — groups are disjoint kd subtrees, so the DFS order of any two of their
+// vertices is the order of the groups, decided by one kd_dfs_first on their first positions.  Ties inside the
+// holder are folded by packet_resolve_ties at the end.
+#define SDFK_PACKET_SLOT_EQ(C_, O_)                                                \
+    {                                                                              \
+        const float dx_ = qx - __uint_as_float(C_[O_]);                            \
+        const float dy_ = qy - __uint_as_float(C_[O_ + 1]);                        \
+        const float dz_ = qz - __uint_as_float(C_[O_ + 2]);                        \
+        const uint32_t du_ = __float_as_uint((dx_ * dx_ + dy_ * dy_) + dz_ * dz_); \
+        eq = eq || du_ == b0;                                                      \
+        s2 = umed3(b, s2, du_);                                                    \
+        b = min(b, du_);                                                           \
+    }
+#define SDFK_PACKET_CHUNK_EQ(C_) \
+    SDFK_PACKET_SLOT_EQ(C_, 0) SDFK_PACKET_SLOT_EQ(C_, 4) SDFK_PACKET_SLOT_EQ(C_, 8) SDFK_PACKET_SLOT_EQ(C_, 12)
+__device__ __forceinline__ void group_exact_lazy(const MeshDev& M, float qx, float qy, float qz, uint32_t cur,
+                                                 ExactState& S) {
+    const uint32_t nch = cur & 15u;
+    const uint32_t first = ((cur & sdfk::KD_REF_MASK) >> 4) << 2;
+    uint32_t b = S.b, s2 = S.s2, h = S.h;
+    const uint32_t b0 = b, h0 = h;
+    bool eq = false;
+    const ChunkPtr C = (ChunkPtr)__builtin_assume_aligned(M.kd_pts4 + first, 64);
+    uint32_t ci = 0;
+    for (; ci + 2u <= nch; ci += 2u) {
+        const u32x16 A0 = C[ci], A1 = C[ci + 1u];
+        SDFK_PACKET_CHUNK_EQ(A0) SDFK_PACKET_CHUNK_EQ(A1)
+    }
+    for (; ci < nch; ++ci) {
+        const u32x16 A0 = C[ci];
+        SDFK_PACKET_CHUNK_EQ(A0)
+    }
+    if (b != b0) {
+        h = cur;  // strictly improved here: the holder is in this group
+    } else if (eq && h0 != H_NONE && h0 != cur) {  // a vertex at the standing minimum: which group comes first?
+        const uint32_t hp = (h0 & KD_LEAF) ? (((h0 & sdfk::KD_REF_MASK) >> 4) << 2) : h0;
+        const bool cur_first = M.fast ? first < hp : (uint32_t)kd_dfs_first(M, qx, qy, qz, (int)hp, (int)first) == first;
+        if (cur_first) h = cur;
+    }
+    S.b = b, S.s2 = s2, S.h = h;
+}
+#undef SDFK_PACKET_CHUNK_EQ
+#undef SDFK_PACKET_SLOT_EQ
 
 // Error model of the approximate pass's estimates (group-centred form, k_apx_fill).  With u = 2^-24, R >= |w| for
 // every stored w = fl(v - cg), t = fl(q - cg), d = |q - v|:  the estimate est = fl(a'' + Qg),
@@ -911,6 +962,23 @@ __device__ __forceinline__ void packet_to_heavy(bool valid, int64_t i, int64_t s
     if (valid) heavy_list[base + (uint32_t)__popcll(vm & lt)] = off + (uint32_t)src;
 }
 
+// packet_resolve for a walk that left exact ties alone (group_exact_lazy): among the vertices of the holder group at
+// distance exactly b, the one nanoflann's DFS meets first (fast_nn: the lowest position, which packet_resolve gives)
+__device__ __forceinline__ int packet_resolve_ties(const MeshDev& M, float qx, float qy, float qz, float bf, uint32_t h) {
+    if (h == H_NONE) return -1;
+    if (!(h & KD_LEAF)) return (int)h;
+    const uint32_t first = ((h & sdfk::KD_REF_MASK) >> 4) << 2, n = 4u * (h & 15u);
+    const uint32_t b = __float_as_uint(bf);
+    int pos = -1;
+    for (uint32_t k = 0; k < n; ++k) {
+        const float4 P = M.kd_pts4[first + k];
+        const float dx = qx - P.x, dy = qy - P.y, dz = qz - P.z;
+        if (__float_as_uint((dx * dx + dy * dy) + dz * dz) == b)
+            pos = pos < 0 ? (int)(first + k) : kd_dfs_first(M, qx, qy, qz, pos, (int)(first + k));
+    }
+    return pos;
+}
+
 // What follows the walk, per lane: the exact second phase (APPROX), the decision whether the walk's answer
 // is nanoflann's, and the result (nearest vertex / incident-face distances / sign).
 template <int KIND, bool ROBUST, bool APPROX>
@@ -954,7 +1022,8 @@ __device__ __forceinline__ void packet_finish(const MeshDev& M, V3 p, bool valid
         pb.s = fminf(__uint_as_float(s2), s_out);
         pos = hp == H_NONE ? -1 : (int)hp;  // (-1: nothing finite, or a fourth candidate group: deferred below)
     } else {
-        pos = packet_resolve(M, p.x, p.y, p.z, pb.b, pb.h);
+        pos = (pb.lazy_ties && pb.s == pb.b && !M.fast) ? packet_resolve_ties(M, p.x, p.y, p.z, pb.b, pb.h)
+                                                         : packet_resolve(M, p.x, p.y, p.z, pb.b, pb.h);
     }
     if (!M.fast) {
         if (valid && (!(pb.s > pb.b * M.amb_c) || !(pb.b >= 1e-30f))) {
@@ -1212,7 +1281,7 @@ __device__ __forceinline__ uint32_t packet_walk_far(const MeshDev& M, float qx, 
         if (APPROX)
             group_approx<false>(M, qx, qy, qz, ref, SA);
         else
-            group_exact(M, qx, qy, qz, ref, SE);
+            group_exact_lazy(M, qx, qy, qz, ref, SE);
         // the origin of everything below: the centre of that group's box (a box that contains everything has centre 0)
         ox = wave_readf(o.cx, g0) + ox, oy = wave_readf(o.cy, g0) + oy, oz = wave_readf(o.cz, g0) + oz;
         if (!(fabsf(ox) <= FLT_MAX && fabsf(oy) <= FLT_MAX && fabsf(oz) <= FLT_MAX)) ox = M.far_c[0], oy = M.far_c[1], oz = M.far_c[2];
@@ -1248,7 +1317,7 @@ __device__ __forceinline__ uint32_t packet_walk_far(const MeshDev& M, float qx, 
             if (APPROX)                                                                                           \
                 group_approx<false>(M, qx, qy, qz, ref_, SA);                                                     \
             else                                                                                                  \
-                group_exact(M, qx, qy, qz, ref_, SE);                                                             \
+                group_exact_lazy(M, qx, qy, qz, ref_, SE);                                                        \
             if (__ballot((APPROX ? __float_as_uint(SA.B1) : SE.b) != old_) != 0ull) {                             \
                 SDFK_FAR_REFRESH()                                                                                \
                 res = SDFK_FAR_RES();                                                                             \
@@ -1318,8 +1387,8 @@ __global__ __launch_bounds__(FAR_BLOCK) SDFK_PK_SGPR void k_query_packet_far(Mes
     ApproxState A = {INF, INF, INF, INF, H_NONE, H_NONE, H_NONE};
     const uint32_t wr = packet_walk_far<APPROX>(M, p.x, p.y, p.z, M.amb_c2, SE, A, M.heavy_budget);
     if (!APPROX) {
-        if (SE.b == SE.tieb) SE.s2 = SE.b;  // a settled exact tie is a tie
         pb.b = __uint_as_float(SE.b), pb.s = __uint_as_float(SE.s2), pb.h = SE.h;
+        pb.lazy_ties = true;
     }
     pb.bailed = wr == 1u;
     if (pb.bailed) {
