@@ -109,17 +109,18 @@ __global__ void k_leaf_boxes(const float4* __restrict__ pn, uint32_t nnodes, uin
 //     fma(t.x, w2.x, fma(t.y, w2.y, fma(t.z, w2.z, W))) + |t|^2,   t = fl(q - cg),
 // whose products are of the size of the group (|w| <= R ~ 0.03), not of the scene: the error is
 // u (14 d^2 + 21 R^2) instead of u (5 S + 4 Q) with S, Q of the order of the scene's squared size (kernels_packet.h).
-// One thread per group; the thread after the last group fills the tail pad.  rmax2_bits[0]: max W over the real
+// One wave per group; the wave after the last group fills the tail pad.  rmax2_bits[0]: max W over the real
 // slots, [1]: set when a finite vertex could not be stored.
-__global__ void k_apx_fill(const uint32_t* __restrict__ grefs, uint32_t ngroups, const float4* __restrict__ gobb_aos,
-                           const float4* __restrict__ pts4, const int32_t* __restrict__ vind, uint32_t npos,
-                           uint32_t nalloc, float4* __restrict__ apx4,
-                           float4* __restrict__ actr, uint32_t* __restrict__ rmax2_bits) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void k_apx_fill(const uint32_t* __restrict__ grefs, uint32_t ngroups,
+                                                 const float4* __restrict__ gobb_aos, const float4* __restrict__ pts4,
+                                                 const int32_t* __restrict__ vind, uint32_t npos, uint32_t nalloc,
+                                                 float4* __restrict__ apx4, float4* __restrict__ actr,
+                                                 uint32_t* __restrict__ rmax2_bits) {
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;  // one wave per group
     const float inf = __builtin_inff();
     if (g == ngroups) {
-        for (uint32_t k = npos; k < nalloc; ++k) apx4[k] = make_float4(0.f, 0.f, 0.f, inf);
-        for (uint32_t k = npos >> 2; k < (nalloc + 3u) >> 2; ++k) actr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t k = npos + lane; k < nalloc; k += 64u) apx4[k] = make_float4(0.f, 0.f, 0.f, inf);
+        for (uint32_t k = (npos >> 2) + lane; k < (nalloc + 3u) >> 2; k += 64u) actr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     if (g > ngroups) return;
@@ -130,7 +131,7 @@ __global__ void k_apx_fill(const uint32_t* __restrict__ grefs, uint32_t ngroups,
     const float cx = okc ? A.x : 0.f, cy = okc ? A.y : 0.f, cz = okc ? A.z : 0.f;
     float rmax2 = 0.f;
     uint32_t wild = 0u;
-    for (uint32_t k = first; k < first + n4; ++k) {
+    for (uint32_t k = first + lane; k < first + n4; k += 64u) {
         const float4 P = pts4[k];
         const float x = P.x - cx, y = P.y - cy, z = P.z - cz;
         const float W = (float)(((double)x * x + (double)y * y) + (double)z * z);
@@ -146,9 +147,15 @@ __global__ void k_apx_fill(const uint32_t* __restrict__ grefs, uint32_t ngroups,
             rmax2 = fmaxf(rmax2, W);
         }
     }
-    for (uint32_t k = first >> 2; k < (first + n4) >> 2; ++k) actr[k] = make_float4(cx, cy, cz, 0.f);
-    atomicMax(rmax2_bits, __float_as_uint(rmax2));  // (non-negative floats order like their bits)
-    if (wild) atomicOr(rmax2_bits + 1, 1u);
+    for (uint32_t k = (first >> 2) + lane; k < (first + n4) >> 2; k += 64u) actr[k] = make_float4(cx, cy, cz, 0.f);
+    for (int o = 32; o >= 1; o >>= 1) {
+        rmax2 = fmaxf(rmax2, __shfl_xor(rmax2, o));
+        wild |= __shfl_xor(wild, o);
+    }
+    if (lane == 0) {
+        atomicMax(rmax2_bits, __float_as_uint(rmax2));  // (non-negative floats order like their bits)
+        if (wild) atomicOr(rmax2_bits + 1, 1u);
+    }
 }
 
 __global__ void k_face_precompute(const float* __restrict__ verts, const uint32_t* __restrict__ faces,

@@ -775,7 +775,7 @@ int reserve_strict_tree(sdfhip_ctx* h, size_t nnodes, size_t nalloc) {
 int fill_apx(sdfhip_ctx* h, uint32_t ngroups, size_t nalloc) {
     hipStream_t s = h->stream;
     HIPC(hipMemsetAsync(h->d_apx_r2, 0, 2 * sizeof(uint32_t), s));
-    k_apx_fill<<<(ngroups + 1u + 255u) / 256u, 256, 0, s>>>(h->d_kd_gref, ngroups, h->d_kd_gobb_aos, h->d_kd_pts4, h->d_kd_vind,
+    k_apx_fill<<<ngroups + 1u, 64, 0, s>>>(h->d_kd_gref, ngroups, h->d_kd_gobb_aos, h->d_kd_pts4, h->d_kd_vind,
                                                           h->kd_npos, (uint32_t)nalloc, h->d_kd_apx4, h->d_kd_actr, h->d_apx_r2);
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(h->apx_r2_bits, h->d_apx_r2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));

@@ -128,7 +128,9 @@ def test_config5_full_size_100_frames():
         best = min(best, (time.perf_counter() - t0) / (frames - warm) * 1e3)
     print(f"config 5, full size, {frames} frames back to back: {best:.2f} ms per frame (update + contains(4M) + nn(4M))")
     if _perf_guards():
-        assert best < 6.0  # 3.6-3.9 ms on an idle MI355X; catches a lost overlap or a slow path
+        # 3.4-3.9 ms on most boxes of the pool, 4.7-5.0 on the slowest seen (the frame is bound by the HOST kd build and
+        # group pass, 1.8-3.0 ms depending on the box's CPU share); catches a lost overlap or a slow path
+        assert best < 6.5
     sub = torch.randint(0, pts.shape[0], (3000,), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
     h = pts[sub].cpu().numpy()
     for t in (0, 1, 24, 50, 75, 99):
