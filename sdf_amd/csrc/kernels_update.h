@@ -102,6 +102,22 @@ __global__ void k_leaf_boxes(const float4* __restrict__ pn, uint32_t nnodes, uin
     }
 }
 
+// The vertices in (padded) tree order: pts4[i] = (v, |v|^2 rounded once from double) for the vertex at tree position i,
+// (3e38, 3e38, 3e38, +inf) for sentinel slots and the tail pad — their distance to anything is +inf.  (The host did
+// this gather and uploaded the result until round 3: a helper thread and 16 B per position over PCIe per update.)
+__global__ void k_tree_positions(const float* __restrict__ verts, const int32_t* __restrict__ vind, uint32_t npos,
+                                 uint32_t nalloc, float4* __restrict__ pts4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nalloc) return;
+    const int32_t vi = i < npos ? vind[i] : -1;
+    if (vi < 0) {
+        pts4[i] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __builtin_inff());
+    } else {
+        const float x = verts[3 * (size_t)vi], y = verts[3 * (size_t)vi + 1], z = verts[3 * (size_t)vi + 2];
+        pts4[i] = make_float4(x, y, z, (float)(((double)x * x + (double)y * y) + (double)z * z));
+    }
+}
+
 // The approximate pass's copy of the vertices, centred per packet group (round 3): group g with centre cg (its
 // box centre; any fp32 point near the group will do) stores per slot  w2 = -2 fl(v - cg)  and  W = |fl(v - cg)|^2
 // (rounded once from double; +inf for sentinel slots and non-finite vertices: their estimate is never a minimum),
@@ -110,12 +126,12 @@ __global__ void k_leaf_boxes(const float4* __restrict__ pn, uint32_t nnodes, uin
 // whose products are of the size of the group (|w| <= R ~ 0.03), not of the scene: the error is
 // u (14 d^2 + 21 R^2) instead of u (5 S + 4 Q) with S, Q of the order of the scene's squared size (kernels_packet.h).
 // One wave per group; the wave after the last group fills the tail pad.  rmax2_bits[0]: max W over the real
-// slots, [1]: set when a finite vertex could not be stored.
+// slots, [1]: set when a finite vertex could not be stored, [2], [3]: density statistics (below).
 __global__ __launch_bounds__(64) void k_apx_fill(const uint32_t* __restrict__ grefs, uint32_t ngroups,
                                                  const float4* __restrict__ gobb_aos, const float4* __restrict__ pts4,
                                                  const int32_t* __restrict__ vind, uint32_t npos, uint32_t nalloc,
                                                  float4* __restrict__ apx4, float4* __restrict__ actr,
-                                                 uint32_t* __restrict__ rmax2_bits) {
+                                                 uint32_t* __restrict__ rmax2_bits, float dens_k) {
     const uint32_t g = blockIdx.x, lane = threadIdx.x;  // one wave per group
     const float inf = __builtin_inff();
     if (g == ngroups) {
@@ -130,9 +146,15 @@ __global__ __launch_bounds__(64) void k_apx_fill(const uint32_t* __restrict__ gr
     const bool okc = fabsf(A.x) <= FLT_MAX && fabsf(A.y) <= FLT_MAX && fabsf(A.z) <= FLT_MAX;
     const float cx = okc ? A.x : 0.f, cy = okc ? A.y : 0.f, cz = okc ? A.z : 0.f;
     float rmax2 = 0.f;
-    uint32_t wild = 0u;
+    uint32_t wild = 0u, cnt = 0u;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (uint32_t k = first + lane; k < first + n4; k += 64u) {
         const float4 P = pts4[k];
+        if (vind[k] >= 0) {
+            ++cnt;
+            lo[0] = fminf(lo[0], P.x), lo[1] = fminf(lo[1], P.y), lo[2] = fminf(lo[2], P.z);
+            hi[0] = fmaxf(hi[0], P.x), hi[1] = fmaxf(hi[1], P.y), hi[2] = fmaxf(hi[2], P.z);
+        }
         const float x = P.x - cx, y = P.y - cy, z = P.z - cz;
         const float W = (float)(((double)x * x + (double)y * y) + (double)z * z);
         if (vind[k] < 0 || !(W <= FLT_MAX)) {  // sentinel slot, or a vertex no finite arithmetic covers
@@ -151,10 +173,21 @@ __global__ __launch_bounds__(64) void k_apx_fill(const uint32_t* __restrict__ gr
     for (int o = 32; o >= 1; o >>= 1) {
         rmax2 = fmaxf(rmax2, __shfl_xor(rmax2, o));
         wild |= __shfl_xor(wild, o);
+        cnt += __shfl_xor(cnt, o);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) lo[d] = fminf(lo[d], __shfl_xor(lo[d], o)), hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
     }
     if (lane == 0) {
         atomicMax(rmax2_bits, __float_as_uint(rmax2));  // (non-negative floats order like their bits)
         if (wild) atomicOr(rmax2_bits + 1, 1u);
+        // vertex density of the group against the pass's window (fill_apx, sdfhip.hip): its vertices over
+        // the disc of its box's half diagonal; [2]: vertices seen (groups of >= 8), [3]: of those in dense groups
+        if (cnt >= 8u) {
+            const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+            const double r2 = 0.25 * (dx * dx + dy * dy + dz * dz);
+            atomicAdd(rmax2_bits + 2, cnt);
+            if (!((double)dens_k * cnt <= r2)) atomicAdd(rmax2_bits + 3, cnt);
+        }
     }
 }
 

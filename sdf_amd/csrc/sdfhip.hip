@@ -183,14 +183,13 @@ struct sdfhip_ctx {
     size_t kd_groups_cap = 0;
     uint32_t n_groups = 0, n_l1 = 0;
     uint32_t* d_kd_split = nullptr;
-    std::vector<float> perm_pts4;  // host staging of kd_pts4, kept across updates
     int32_t* d_kd_vind = nullptr;
     size_t kd_nodes_cap = 0, kd_pos_cap = 0;
     float4* d_kd_pts4 = nullptr;
     float4* d_kd_apx4 = nullptr;  // the approximate pass's group-centred copy (k_apx_fill) ...
     float4* d_kd_actr = nullptr;  // ... the groups' centres, one per 4 positions ...
     uint32_t* d_apx_r2 = nullptr; // ... and [0] the largest squared group radius (bits of a float), [1] != 0: unusable
-    uint32_t apx_r2_bits[2] = {0, 0};
+    uint32_t apx_r2_bits[4] = {0, 0, 0, 0};
     bool apx_usable = false;      // false: a vertex the pass cannot represent (k_apx_fill); the exact walk is taken
     float apx_k1 = 0.f, apx_e0 = 0.f;  // error model of the pass: E(est) = apx_k1 est + apx_e0 (fill_apx)
     float4* d_kd_lbox = nullptr;  // per position: its leaf's tight box (k_leaf_boxes, kd_path_clear)
@@ -710,36 +709,6 @@ bool approx_pays(const sdfhip_ctx* h) {
     if (!approx_window(h, E, lambda)) return false;
     return lambda <= APPROX_LAMBDA_MAX;
 }
-// The same question per packet group, once the groups exist: a mesh whose vertices crowd in one place (a fine
-// part in a coarse scene) passes the average test while every query that has the fine part nearest meets four
-// candidate groups and goes to the exact scan — a pass over all vertices each.  Density of a group: its vertices
-// over the disc of its box's half diagonal.  Every fourth group is looked at; more than 2 % of the vertices seen
-// in groups denser than four times the limit on the average turn the pass off (a torus is twice as dense inside
-// as outside, and the limit on the average was tuned on tori).
-bool approx_pays_locally(const sdfhip_ctx* h) {
-    double E, lambda;
-    if (!approx_window(h, E, lambda)) return false;
-    const float* P = h->perm_pts4.data();
-    size_t seen = 0, dense = 0;
-    for (size_t g = 0; g < h->kd.groups.size(); g += 4) {
-        const uint32_t ref = h->kd.groups[g];
-        const size_t first = (size_t)((ref & sdfk::KD_REF_MASK) >> 4) << 2, n = 4u * (ref & 15u);
-        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        uint32_t cnt = 0;
-        for (size_t k = first; k < first + n; ++k) {
-            if (!(P[4 * k + 3] < FLT_MAX)) continue;  // sentinel slot
-            ++cnt;
-            for (int d = 0; d < 3; ++d) lo[d] = std::fmin(lo[d], P[4 * k + d]), hi[d] = std::fmax(hi[d], P[4 * k + d]);
-        }
-        if (cnt < 8) continue;
-        seen += cnt;
-        const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
-        const double r2 = 0.25 * (dx * dx + dy * dy + dz * dz);
-        if (!(2.0 * E * cnt <= 4.0 * APPROX_LAMBDA_MAX * r2)) dense += cnt;
-    }
-    return dense * 50 <= seen;
-}
-
 // device arrays of the strict tree: `nnodes` internal nodes, `nalloc` padded positions.  d_kd_pts4 / d_kd_vind are
 // shared with the GPU-built tree of fast_nn (build_fast_tree grows them under kd_pos_cap); the approximate pass's
 // copy and the leaf boxes exist in strict mode only and keep capacities of their own — a fast_nn update may have
@@ -759,7 +728,7 @@ int reserve_strict_tree(sdfhip_ctx* h, size_t nnodes, size_t nalloc) {
         if (int rc = dalloc(&h->d_kd_apx4, nalloc)) return rc;
         if (int rc = dalloc(&h->d_kd_actr, nalloc / 4 + 4)) return rc;
         if (!h->d_apx_r2)
-            if (int rc = dalloc(&h->d_apx_r2, 2)) return rc;
+            if (int rc = dalloc(&h->d_apx_r2, 4)) return rc;
         h->kd_apx_cap = nalloc;
     }
     if (nalloc > h->kd_lbox_cap) {
@@ -774,11 +743,21 @@ int reserve_strict_tree(sdfhip_ctx* h, size_t nnodes, size_t nalloc) {
 // |fl(v - cg)|^2 the kernel met.  Synchronizes the stream.
 int fill_apx(sdfhip_ctx* h, uint32_t ngroups, size_t nalloc) {
     hipStream_t s = h->stream;
-    HIPC(hipMemsetAsync(h->d_apx_r2, 0, 2 * sizeof(uint32_t), s));
+    // The window of the pass held against the density of each packet group (its vertices over the disc of its box's half
+    // diagonal): a mesh whose vertices crowd in one place (a fine part in a coarse scene) passes the average test
+    // of approx_pays() while every query that has the fine part nearest meets four candidate groups and goes to the
+    // exact scan — a pass over all vertices each (424^2 torus + a copy shrunk to 1 % beside it, 32M random points: nn
+    // 195 ms with the pass, 39 ms without).  More than 2 % of the vertices in groups denser than four times the limit
+    // on the average turn the pass off (a torus is twice as dense inside as outside, and the limit on the average
+    // was tuned on tori).  Counted by k_apx_fill, one wave per group.
+    double E = 0.0, lambda = 0.0;
+    const bool have_window = approx_window(h, E, lambda);
+    const float dens_k = have_window ? (float)(2.0 * E / (4.0 * APPROX_LAMBDA_MAX)) : 0.f;
+    HIPC(hipMemsetAsync(h->d_apx_r2, 0, 4 * sizeof(uint32_t), s));
     k_apx_fill<<<ngroups + 1u, 64, 0, s>>>(h->d_kd_gref, ngroups, h->d_kd_gobb_aos, h->d_kd_pts4, h->d_kd_vind,
-                                                          h->kd_npos, (uint32_t)nalloc, h->d_kd_apx4, h->d_kd_actr, h->d_apx_r2);
+                                          h->kd_npos, (uint32_t)nalloc, h->d_kd_apx4, h->d_kd_actr, h->d_apx_r2, dens_k);
     HIPC(hipGetLastError());
-    HIPC(hipMemcpyAsync(h->apx_r2_bits, h->d_apx_r2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPC(hipMemcpyAsync(h->apx_r2_bits, h->d_apx_r2, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
     float r2;
     std::memcpy(&r2, &h->apx_r2_bits[0], sizeof r2);
@@ -792,11 +771,11 @@ int fill_apx(sdfhip_ctx* h, uint32_t ngroups, size_t nalloc) {
     h->apx_usable = h->apx_r2_bits[1] == 0u && std::isfinite(h->apx_e0);
     // The absolute term alone as a window (approx_window): one stray group as wide as the scene makes every query
     // ambiguous.  (Followers of a group take the same decision from the same data.)
-    double E, lambda;
-    if (h->approx_ok && approx_window(h, E, lambda)) {
+    if (h->approx_ok && have_window) {
         lambda *= (double)h->apx_e0 / E;
         if (!(lambda <= APPROX_LAMBDA_MAX)) h->approx_ok = false;
     }
+    if (!have_window || (uint64_t)h->apx_r2_bits[3] * 50u > (uint64_t)h->apx_r2_bits[2]) h->approx_ok = false;  // (locally dense)
     if (!h->apx_usable) h->approx_ok = false;
     if (std::getenv("SDFHIP_DEBUG"))
         std::fprintf(stderr, "[sdfhip] approximate pass: largest group radius^2 %.4g, e0 %.4g, usable %d, on %d\n", (double)r2,
@@ -902,26 +881,8 @@ int do_update(sdfhip_ctx* h, bool draw_R, UpdateSync* sync = nullptr) {
     // vertices in (padded) tree order; sentinel slots are far away: their distance is +inf
     const size_t npos = h->kd.pos_vert.size();
     const size_t nalloc = npos + 16;
-    auto fill = std::async(std::launch::async, [h, npos, nalloc]() {
-        h->perm_pts4.resize(4 * nalloc);
-        float* dst = h->perm_pts4.data();
-        for (size_t i = 0; i < nalloc; ++i) {
-            const int32_t vi = i < npos ? h->kd.pos_vert[i] : -1;
-            if (vi < 0) {
-                dst[4 * i] = dst[4 * i + 1] = dst[4 * i + 2] = 3.0e38f;
-                dst[4 * i + 3] = __builtin_inff();
-            } else {
-                const float* src = h->h_verts + 3 * (size_t)vi;
-                dst[4 * i] = src[0], dst[4 * i + 1] = src[1], dst[4 * i + 2] = src[2];
-                // (w: finite for a vertex, +inf for a sentinel; k_apx_fill tells them apart by it)
-                dst[4 * i + 3] = (float)(((double)src[0] * src[0] + (double)src[1] * src[1]) + (double)src[2] * src[2]);
-            }
-        }
-    });
     auto tq0 = std::chrono::steady_clock::now();
     h->kd.build_groups();
-    fill.get();
-    if (h->approx_ok) h->approx_ok = approx_pays_locally(h);
     auto tq1 = std::chrono::steady_clock::now();
     const int rc_dev = dev_side.get();
     auto tq2 = std::chrono::steady_clock::now();
@@ -942,8 +903,8 @@ int do_update(sdfhip_ctx* h, bool draw_R, UpdateSync* sync = nullptr) {
     if (npos)
         HIPC(hipMemcpyAsync(h->d_kd_vind, h->kd.pos_vert.data(), sizeof(int32_t) * npos,
                             hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpyAsync(h->d_kd_pts4, h->perm_pts4.data(), sizeof(float) * 4 * nalloc,
-                        hipMemcpyHostToDevice, s));
+    k_tree_positions<<<(uint32_t)((nalloc + 255) / 256), 256, 0, s>>>(h->d_verts, h->d_kd_vind, (uint32_t)npos, (uint32_t)nalloc,
+                                                                     h->d_kd_pts4);
     if (!h->kd.nodes.empty()) {
         HIPC(hipMemcpyAsync(h->d_kd_pn, h->kd.nodes.data(), sizeof(sdfk::KdNodeH) * h->kd.nodes.size(),
                             hipMemcpyHostToDevice, s));
