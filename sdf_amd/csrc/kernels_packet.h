@@ -192,7 +192,10 @@ __device__ __forceinline__ float wave_readf(float v, uint32_t l) {
 // ends with the same (b, s, h) / (B1..B4, H1..H3) as the tree walk it replaces.
 // =========================================================================================
 constexpr float PK_EPS = 3.8146973e-6f;  // 2^-18
-constexpr uint32_t CUBE_CAP = 512;        // entries of one cube's list (eight wide tests: still half the walk's); longer: the cube is unusable
+#ifndef SDFK_CUBE_CAP
+#define SDFK_CUBE_CAP 512
+#endif
+constexpr uint32_t CUBE_CAP = SDFK_CUBE_CAP;        // entries of one cube's list (eight wide tests: still half the walk's); longer: the cube is unusable
 constexpr uint32_t CUBE_NONE = 0xFFFFFFFFu;
 struct ObbLane {
     float dP;                 // squared distance from the packet centre to this lane's child box (lower bound)
