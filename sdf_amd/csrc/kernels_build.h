@@ -149,7 +149,10 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ pts, i
 // are 2 KB each: the 3-D order moved 6 TB/s for them).  r0, r1: rows of R giving x', y'.
 // far queries of a batch (kernels_packet.h, k_query_packet_far): centre and squared radius of the near region
 struct FarKey {
-    float c[3], r2;  // r2 == 0: off
+    float c[3], r2;    // r2: squared far radius for a dense batch; 0: off
+    float r2_sparse;   // ... for a sparse one
+    float rho_dense, rho_sparse;  // packet radius (half the edge of a cube holding 64 points of the batch) up to which the
+                                  // batch counts as dense / from which as sparse; in between the radius is interpolated
 };
 struct ColumnKey {
     int on;
@@ -176,8 +179,23 @@ __global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __rest
     // ones by their Morton code over the near box instead of the batch's bounds (which may be hundreds of meshes wide).
     bool far_on = false;
     uint32_t nfar = 0;
+    float far_r2 = 0.f;
     if (!CK.on && FK.r2 > 0.f) {
-        const float rf = __builtin_sqrtf(FK.r2);
+        // The far radius follows the batch's density.  64 Morton neighbours of a dense batch stay a compact packet at
+        // any distance and the spatial walk serves them well out to six half diagonals (closer in, the cap of the mesh
+        // facing a query is large and the far walk evaluates too much: 8M points in a box +-4 around the unit torus,
+        // far radius 2 / 6 half diagonals: 14.2 / 4.2 ms); a sparse batch's packets are wide wherever they lie, walk
+        // badly or not at all, and the far walk takes over from two half diagonals on (8M points in +-30: 6.4 against
+        // 7.1 ms, 1M points in +-16: 3.5 against 4.5).  Every block computes the same radius from the batch's bounds;
+        // block 0 leaves it in b[7] for the packet kernels.
+        float vol = 1.f;
+        for (int d = 0; d < 3; ++d) vol *= fmaxf(ord2f(b[3 + d]) - ord2f(b[d]), 0.f);
+        const float rho = 0.5f * cbrtf(64.f * vol / (float)n);
+        float t = (rho - FK.rho_dense) / (FK.rho_sparse - FK.rho_dense);
+        t = t >= 0.f ? (t <= 1.f ? t : 1.f) : 0.f;  // (NaN: dense)
+        const float rf = __builtin_sqrtf(FK.r2) + t * (__builtin_sqrtf(FK.r2_sparse) - __builtin_sqrtf(FK.r2));
+        far_r2 = rf * rf;
+        if (blockIdx.x == 0 && threadIdx.x == 0) b[7] = __float_as_uint(far_r2);
         for (int d = 0; d < 3; ++d) far_on = far_on || !(ord2f(b[d]) >= FK.c[d] - rf) || !(ord2f(b[3 + d]) <= FK.c[d] + rf);
         if (far_on)
             for (int d = 0; d < 3; ++d) lo[d] = FK.c[d] - rf, inv[d] = 512.f / rf;
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __rest
             } else {
                 key = morton30(x[k], y[k], z[k], lo, inv) >> key_shift;
                 if (far_on) {
-                    const uint32_t sh = far_shell(FK.c, FK.r2, x[k], y[k], z[k]);
+                    const uint32_t sh = far_shell(FK.c, far_r2, x[k], y[k], z[k]);
                     key >>= 1;  // near: the top bit stays clear
                     if (sh) {
                         ++nfar;

@@ -1090,7 +1090,7 @@ __device__ __forceinline__ uint32_t far_shell(const float c[3], float r2, float 
 // every lane's query is far and of the same shell (lanes past the end repeat the last query)
 __device__ __forceinline__ bool far_packet(const MeshDev& M, float x, float y, float z, int64_t pkt, int64_t n) {
     if (pkt < (int64_t)M.far_lo || 64 * pkt < n - (int64_t)*M.far_cnt) return false;
-    const uint32_t sh = far_shell(M.far_c, M.far_r2, x, y, z);
+    const uint32_t sh = far_shell(M.far_c, __uint_as_float(M.far_cnt[1]), x, y, z);  // (the radius the key kernel chose)
     const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh);
     return s0 != 0u && __ballot(sh != s0) == 0ull;
 }

@@ -214,6 +214,7 @@ struct sdfhip_ctx {
     int64_t opt_cube_min = 8 << 20;
     int64_t opt_cube_level = 0;    // cubes per axis = 2^level; 0 automatic (~4096 queries per cube)
     int64_t opt_far = 1;      // packet pass: far packets (k_query_packet_far); option "far_packets"
+    int64_t opt_far_sparse_x10 = 20;  // ... from this many tenths on in a sparse batch; option "far_radius_sparse_x10"
     int64_t opt_far_x10 = 60; // ... from this many tenths of the mesh's half diagonal on; option "far_radius_x10"
     int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
     bool approx_ok = false;   // decided by every update(): see approx_pays()
@@ -1287,8 +1288,13 @@ int run_query_t(sdfhip_ctx* h, const float* d_pts, int64_t n, int trunc, void* d
             const uint32_t ntiles = (uint32_t)((m + RS_TILE - 1) / RS_TILE);
             const int key_bits = CK.on ? 24 : (int)h->opt_sort_bits;
             // far queries sort behind the near ones, by direction, when the packet pass will walk them as far packets
-            FarKey FK = {{M.far_c[0], M.far_c[1], M.far_c[2]}, 0.f};
-            if (far_ok && !CK.on) FK.r2 = far_r2;
+            FarKey FK = {{M.far_c[0], M.far_c[1], M.far_c[2]}, 0.f, 0.f, 0.f, 1.f};
+            if (far_ok && !CK.on) {
+                const double hd = std::sqrt((double)far_r2) / (0.1 * (double)h->opt_far_x10);  // half diagonal of the mesh AABB
+                const double rs = 0.1 * (double)std::min(h->opt_far_sparse_x10, h->opt_far_x10) * hd;
+                FK.r2 = far_r2, FK.r2_sparse = (float)(rs * rs);
+                FK.rho_dense = (float)(0.10 * hd), FK.rho_sparse = (float)(0.16 * hd);
+            }
             k_query_morton<<<ntiles, RS_THREADS, 0, s>>>(p, (uint32_t)m, W.qbounds, W.qkeys, W.sorter.hist, ntiles, CK, 30 - key_bits, FK);
             uint32_t* sorted_perm = nullptr;
             if (int rc = W.sorter.sort(W.qkeys, W.qperm, (uint32_t)m, key_bits, 1, s, nullptr, &sorted_perm, false, true))
@@ -2222,6 +2228,8 @@ int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t v) {
         h->opt_sort = v;
     else if (!strcmp(key, "far_packets"))
         h->opt_far = v;
+    else if (!strcmp(key, "far_radius_sparse_x10"))
+        h->opt_far_sparse_x10 = v < 11 ? 11 : v;
     else if (!strcmp(key, "far_radius_x10"))
         h->opt_far_x10 = v < 11 ? 11 : v;
     else if (!strcmp(key, "profile")) {
