@@ -314,7 +314,7 @@ int sdfhip_host_free(void* p);
  * launch), "cube_level" (2^level cubes per axis; 0 = automatic, default: cube edge ~1.3 x the size of a vertex group),
  * "sort_bits" (Morton key bits of the query sort: 24 (default, three radix passes) or 30 (four)),
  * "far_packets" (1, default: in a sorted launch that reaches beyond the near region of the mesh, queries farther than
- * "far_radius_x10" tenths (default 60; "far_radius_sparse_x10", default 20, in a sparse batch) of the half diagonal of the mesh's box from its centre are sorted by distance shell and
+ * "far_radius_x10" tenths (default 120; "far_radius_sparse_x10", default 20, in a sparse batch) of the half diagonal of the mesh's box from its centre are sorted by distance shell and
  * direction and walked by a kernel of their own; 0: the strict kernel answers them, one tree walk per query).
  * No option changes a result, except "fast_nn" as described. */
 int sdfhip_set_option(sdfhip_t* h, const char* key, int64_t value);

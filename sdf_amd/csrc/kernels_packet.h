@@ -1357,12 +1357,14 @@ __device__ __forceinline__ uint32_t packet_walk_far(const MeshDev& M, float qx, 
 // packet npk - 1 - b if that packet is a far packet, and leaves otherwise — as the main kernel leaves every far
 // packet from M.far_lo on to this one.  Launched with min(npk, FAR_CAP) blocks behind the main kernel.
 // far_cnt: the far queries of the launch as the key kernel counted them (they hold the last sorted positions): blocks
-// whose packets lie before them leave at once — a launch without far queries pays FAR_CAP / 4 empty blocks.
-constexpr uint32_t FAR_CAP = 1u << 19;  // packets (32M far queries of one launch; more: the rest takes the old way)
+// whose packets lie before them leave at once — a launch without far queries pays one empty block per four packets.
+constexpr uint32_t FAR_CAP = 1u << 21;  // packets (2^27 queries: the largest chunk of a call)
 #ifndef SDFK_FAR_BLOCK
 #define SDFK_FAR_BLOCK 256
 #endif
-constexpr int FAR_BLOCK = SDFK_FAR_BLOCK;  // (256: four packets per block)
+constexpr int FAR_BLOCK = SDFK_FAR_BLOCK;  // (four packets per block; 64 / 128 / 256 walk alike, 1024 is 20 % slower: a block holds
+                                           // its slots until its slowest wave is through; the empty blocks of a launch without
+                                           // far queries cost 0.1 ms per 500k, i.e. per 125M points)
 template <int KIND, bool ROBUST, bool APPROX>
 __global__ __launch_bounds__(FAR_BLOCK) SDFK_PK_SGPR void k_query_packet_far(MeshDev M, const float* __restrict__ pts,
                                                              const uint32_t* __restrict__ perm, int64_t n,

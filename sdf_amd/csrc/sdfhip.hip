@@ -215,7 +215,7 @@ struct sdfhip_ctx {
     int64_t opt_cube_level = 0;    // cubes per axis = 2^level; 0 automatic (~4096 queries per cube)
     int64_t opt_far = 1;      // packet pass: far packets (k_query_packet_far); option "far_packets"
     int64_t opt_far_sparse_x10 = 20;  // ... from this many tenths on in a sparse batch; option "far_radius_sparse_x10"
-    int64_t opt_far_x10 = 60; // ... from this many tenths of the mesh's half diagonal on; option "far_radius_x10"
+    int64_t opt_far_x10 = 120; // ... from this many tenths of the mesh's half diagonal on; option "far_radius_x10"
     int64_t opt_approx = -1;  // packet pass, approximate first pass: -1 automatic (approx_ok), 0 off, 1 on
     bool approx_ok = false;   // decided by every update(): see approx_pays()
     bool approx_pre = false;  // ... its value when the tree was uploaded (fill_apx may still turn it off; read by followers)
@@ -941,9 +941,12 @@ int do_update(sdfhip_ctx* h, bool draw_R, UpdateSync* sync = nullptr) {
     return 0;
 }
 
-// far packets (kernels_packet.h): squared radius of the near region — six half diagonals of the mesh AABB around its
-// centre (8M points in a box +-4 / +-8 / +-30 around the unit torus, nn: 2 half diagonals 14.2 / 10.6 / 6.3 ms, 4.5: 4.4 / 7.3 /
-// 6.7, 6: 4.25 / 6.9 / 6.9, 9: 4.2 / 6.2 / 8.8; closer in, the cap facing a query is too large for this walk); 0: no far packets
+// far packets (kernels_packet.h): squared radius of the near region of a DENSE batch — twelve half diagonals of the mesh
+// AABB around its centre; the key kernel shortens it to two for a sparse batch (k_query_morton).  8M points in a box
+// +-4 / +-8 / +-30 around the unit torus with one radius for all batches, nn: 2 half diagonals 14.2 / 10.6 / 6.3 ms,
+// 4.5: 4.4 / 7.3 / 6.7, 6: 4.25 / 6.9 / 6.9, 9: 4.2 / 6.2 / 8.8 — closer in, the cap facing a query is too large for the
+// far walk while a dense batch's spatial packets still do well; with the sparse radius apart, 6 / 12 for dense
+// batches: +-8 8M points 7.3 / 6.1 ms, +-16 64M points 35.1 / 29.4.  0: no far packets
 float far_radius2(const sdfhip_ctx* h) {
     double r2 = 0.0;
     for (int d = 0; d < 3; ++d) {

@@ -1,5 +1,5 @@
-"""Far packets (kernels_packet.h: k_query_packet_far, option "far_packets"): queries farther from the mesh than six
-half diagonals of its box are sorted by distance shell and direction and walked with bounds made for them.  A walk
+"""Far packets (kernels_packet.h: k_query_packet_far, option "far_packets"): queries farther from the mesh than twelve
+half diagonals of its box (two in a sparse batch) are sorted by distance shell and direction and walked with bounds made for them.  A walk
 may only skip what is farther than a lane's threshold, so results must not depend on it: bit-equal to the oracle
 (oracle/pyoracle.py <- reference sdf.cpp:110-160 / nanoflann.hpp) and to the same handle with far_packets=0, for
 batches that mix near and far queries, shells, directions along the axes, meshes off the origin, lists forced on."""
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def _mixed_queries(rng, c, r, n):
     """near box, shells out to 2^7 far radii and beyond, axis directions, points on shell boundaries"""
-    far = 6.0 * r
+    far = 2.0 * r  # (the sparse far radius; the dense one is 12 r: the shells below reach past both)
     parts = [c + rng.uniform(-1.2 * r, 1.2 * r, (n, 3))]
     for k in range(0, 9):
         d = rng.normal(size=(n // 4, 3))
