@@ -182,7 +182,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_query_morton(const float* __rest
     float far_r2 = 0.f;
     if (!CK.on && FK.r2 > 0.f) {
         // The far radius follows the batch's density.  64 Morton neighbours of a dense batch stay a compact packet at
-        // any distance and the spatial walk serves them well out to six half diagonals (closer in, the cap of the mesh
+        // any distance and the spatial walk serves them well out to twelve half diagonals (closer in, the cap of the mesh
         // facing a query is large and the far walk evaluates too much: 8M points in a box +-4 around the unit torus,
         // far radius 2 / 6 half diagonals: 14.2 / 4.2 ms); a sparse batch's packets are wide wherever they lie, walk
         // badly or not at all, and the far walk takes over from two half diagonals on (8M points in +-30: 6.4 against
